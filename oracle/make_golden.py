@@ -1,0 +1,227 @@
+"""Generates tests/golden/*.npz from the REAL reference (build container only).
+
+    python oracle/make_golden.py            # all fixtures
+    python oracle/make_golden.py tiny       # subset by name prefix
+
+For every case the reference model (imported read-only from /root/reference through
+oracle/_reference_loader.py) and the CPU restatement (oracle/mvit_oracle.py) are run on the same
+synthetic weights/clip (aicity_action_amd.utils.synth) and must agree to <=1e-5 before anything is
+written -- this is what pins the oracle.  Fixtures hold plain arrays only (inputs are regenerated
+from seeds; outputs are stored, large tensors as strided samples + moments).
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import mvit_oracle as O  # noqa: E402
+from _reference_loader import (REFERENCE_ROOT, build_reference_model, load_reference,  # noqa: E402
+                               reference_cfg)
+from aicity_action_amd.utils.synth import load_synth_weights, synth_clip  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+MAX_SAMPLE = 2048
+
+TINY = {
+    "MVIT.DEPTH": 4,
+    "MVIT.DIM_MUL": [[1, 2.0], [3, 2.0]],
+    "MVIT.HEAD_MUL": [[1, 2.0], [3, 2.0]],
+    "MVIT.POOL_Q_STRIDE": [[1, 1, 2, 2], [3, 1, 2, 2]],
+    "MVIT.POOL_KV_STRIDE_ADAPTIVE": [1, 4, 4],
+    "DATA.NUM_FRAMES": 4,
+}
+CASES = {
+    # name: (yaml, overrides, batch, clip seed)
+    "tiny_even": ("MVITV2_FULL_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 64, "DATA.TEST_CROP_SIZE": 64}), 2, 11),
+    "tiny_odd": ("MVITV2_FULL_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 56, "DATA.TEST_CROP_SIZE": 56}), 3, 12),
+    "full224": ("MVITV2_FULL_B_16x4_CONV.yaml", {}, 1, 1),
+    "full448": ("MVITV2_FULL_B_16x4_CONV_448.yaml", {}, 1, 2),
+}
+
+
+def sample(t):
+    """Strided sample of a tensor (<= MAX_SAMPLE elements) + first two moments."""
+    f = t.detach().reshape(-1).to(torch.float32)
+    stride = max(1, (f.numel() + MAX_SAMPLE - 1) // MAX_SAMPLE)
+    return f[::stride].numpy().copy(), np.array([f.mean().item(), f.abs().mean().item(), stride, f.numel()], np.float64)
+
+
+def mvit_dict(cfg):
+    return copy.deepcopy({k: cfg.MVIT[k] for k in cfg.MVIT})
+
+
+def run_case(name):
+    yaml_name, ov, batch, clip_seed = CASES[name]
+    cfg = reference_cfg(yaml_name, ov)
+    mv = mvit_dict(cfg)
+    model = build_reference_model(cfg).eval()
+    load_synth_weights(model, 0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    clip = synth_clip(batch, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, clip_seed)
+
+    # --- reference taps via hooks ---------------------------------------------------------
+    ref = {}
+    hooks = [model.head.projection.register_forward_hook(lambda m, i, o: ref.__setitem__("logits", o.detach())),
+             model.norm.register_forward_hook(lambda m, i, o: ref.__setitem__("final_norm", o.detach()))]
+    for i, blk in enumerate(model.blocks):
+        def _blk_hook(m, inp, out, i=i):
+            ref["block%d" % i] = out[0].detach()
+            ref["thw%d" % i] = list(out[1])
+        hooks.append(blk.register_forward_hook(_blk_hook))
+    hooks.append(model.blocks[0].register_forward_pre_hook(lambda m, inp: ref.__setitem__("stem", inp[0].detach())))
+    with torch.no_grad():
+        probs = model([clip])
+    for h in hooks:
+        h.remove()
+
+    # --- oracle --------------------------------------------------------------------------
+    taps = {}
+    with torch.no_grad():
+        o_probs, o_logits = O.forward(sd, clip, mv, taps=taps)
+    d_log = (o_logits - ref["logits"]).abs().max().item()
+    d_prob = (o_probs - probs).abs().max().item()
+    assert d_log <= 1e-5 and d_prob <= 1e-5, (name, d_log, d_prob)
+    for k in ["stem", "final_norm"] + ["block%d" % i for i in range(len(model.blocks))]:
+        d = (taps[k] - ref[k]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, ref[k].abs().max().item()), (name, k, d)
+    for i in range(len(model.blocks)):
+        assert list(taps["thw%d" % i]) == list(ref["thw%d" % i])
+    print("[%s] oracle==reference: logits %.2e probs %.2e" % (name, d_log, d_prob))
+
+    out = {"logits": ref["logits"].numpy(), "probs": probs.numpy()}
+    for k, v in taps.items():
+        if k.startswith("thw"):
+            out[k] = np.array(v, np.int64)
+        else:
+            s, mom = sample(v)
+            out["tap." + k] = s
+            out["mom." + k] = mom
+    meta = {"yaml": yaml_name, "overrides": ov, "batch": batch, "clip_seed": clip_seed, "weight_seed": 0,
+            "num_frames": cfg.DATA.NUM_FRAMES, "crop": cfg.DATA.TRAIN_CROP_SIZE,
+            "n_params": int(sum(p.numel() for p in model.parameters())),
+            "state_keys": list(sd.keys()), "state_shapes": [list(v.shape) for v in sd.values()]}
+
+    # --- train step (tiny cases only): loss, grads, one clipped AdamW step -----------------
+    if name.startswith("tiny"):
+        ov2 = dict(ov, **{"MVIT.DROPPATH_RATE": 0.0, "MODEL.DROPOUT_RATE": 0.0})
+        cfg2 = reference_cfg(yaml_name, ov2)
+        mv2 = mvit_dict(cfg2)
+        m2 = build_reference_model(cfg2).train()
+        load_synth_weights(m2, 0)
+        labels = torch.zeros(batch, cfg2.MODEL.NUM_CLASSES)
+        for b in range(batch):
+            labels[b, (3 * b + 1) % cfg2.MODEL.NUM_CLASSES] = 0.9
+            labels[b, (5 * b + 2) % cfg2.MODEL.NUM_CLASSES] = 0.1
+        from slowfast.models import optimizer as ref_optim
+        from slowfast.models.losses import get_loss_func
+        from slowfast.utils.lr_policy import get_lr_at_epoch
+        opt = ref_optim.construct_optimizer(m2, cfg2)
+        cur_epoch = 0.25
+        lr = get_lr_at_epoch(cfg2, cur_epoch)
+        ref_optim.set_lr(opt, lr)
+        preds = m2([clip])
+        loss = get_loss_func(cfg2.MODEL.LOSS_FUNC)(reduction="mean")(preds, labels)
+        opt.zero_grad()
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(m2.parameters(), cfg2.SOLVER.CLIP_GRAD_L2NORM)
+        grads = {k: p.grad.detach().clone() for k, p in m2.named_parameters()}  # post-clip (in place)
+        opt.step()
+        # oracle side
+        sd2 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        o_out, o_lg = O.forward(sd2, clip, mv2, training=True)
+        o_loss = O.soft_target_cross_entropy(o_out, labels)
+        o_loss.backward()
+        assert abs(o_loss.item() - loss.item()) <= 1e-6, (o_loss.item(), loss.item())
+        assert abs(O.lr_at_epoch({k: cfg2.SOLVER[k] for k in cfg2.SOLVER}, cur_epoch) - lr) < 1e-12
+        tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd2.values())).item()
+        assert abs(tot - gnorm.item()) <= 1e-5 * max(1.0, tot), (tot, gnorm.item())
+        coef = min(1.0, cfg2.SOLVER.CLIP_GRAD_L2NORM / (tot + 1e-6))
+        for k in grads:
+            d = (sd2[k].grad * coef - grads[k]).abs().max().item()
+            assert d <= 1e-5 * max(1.0, grads[k].abs().max().item()) + 1e-7, (k, d)
+        print("[%s] oracle grads==reference grads (loss %.6f, |g| %.4f, lr %.3e)" % (name, loss.item(), tot, lr))
+        out["train.labels"] = labels.numpy()
+        out["train.loss"] = np.array(loss.item(), np.float64)
+        out["train.logits"] = preds.detach().numpy()
+        out["train.grad_norm"] = np.array(gnorm.item(), np.float64)
+        out["train.lr"] = np.array(lr, np.float64)
+        groups = [[], []]
+        name_of = {id(p): k for k, p in m2.named_parameters()}
+        for gi, g in enumerate(opt.param_groups):
+            for p in g["params"]:
+                groups[0 if g["weight_decay"] > 0 else 1].append(name_of[id(p)])
+        meta["wd_group"] = groups[0]
+        meta["no_wd_group"] = groups[1]
+        meta["train_overrides"] = ov2
+        meta["weight_decay"] = cfg2.SOLVER.WEIGHT_DECAY
+        meta["clip"] = cfg2.SOLVER.CLIP_GRAD_L2NORM
+        meta["solver"] = {k: cfg2.SOLVER[k] for k in cfg2.SOLVER}
+        new_sd = m2.state_dict()
+        for k in grads:
+            s, mom = sample(grads[k])
+            out["grad." + k] = s
+            out["gmom." + k] = mom
+            s, mom = sample(new_sd[k])
+            out["step." + k] = s
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(GOLD, "mvit_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def run_arith():
+    """G3: stage arithmetic tables for every configs/Aicity yaml (pins spec derivation)."""
+    table = {}
+    for y in sorted(f for f in os.listdir(os.path.join(REFERENCE_ROOT, "configs", "Aicity")) if f.endswith(".yaml")):
+        cfg = reference_cfg(y)
+        mv = mvit_dict(cfg)
+        model = build_reference_model(cfg)
+        blocks = []
+        thw = [cfg.DATA.NUM_FRAMES // cfg.MVIT.PATCH_STRIDE[0]] + [cfg.DATA.TRAIN_CROP_SIZE // s for s in cfg.MVIT.PATCH_STRIDE[1:]]
+        for i, b in enumerate(model.blocks):
+            a = b.attn
+            blocks.append({
+                "dim_in": b.norm1.normalized_shape[0], "dim_out": b.dim_out, "heads": a.num_heads,
+                "stride_q": list(a.pool_q.stride) if getattr(a, "pool_q", None) is not None else [],
+                "stride_kv": list(a.pool_k.stride) if getattr(a, "pool_k", None) is not None else [],
+                "skip": [list(b.pool_skip.kernel_size), list(b.pool_skip.stride), list(b.pool_skip.padding)]
+                if b.pool_skip is not None else None,
+                "has_pmp": hasattr(b, "proj_max_pool"),
+                "drop_path": float(b.drop_path.drop_prob) if hasattr(b.drop_path, "drop_prob") else 0.0,
+            })
+        sd = model.state_dict()
+        from slowfast.models import optimizer as ref_optim
+        opt = ref_optim.construct_optimizer(model, cfg)
+        table[y] = {"blocks": blocks, "n_params": int(sum(p.numel() for p in model.parameters())),
+                    "keys": list(sd.keys()), "shapes": [list(v.shape) for v in sd.values()],
+                    "pool_kv_stride": [list(map(int, e)) for e in cfg.MVIT.POOL_KV_STRIDE],
+                    "group_sizes": [len(g["params"]) for g in opt.param_groups],
+                    "group_wd": [g["weight_decay"] for g in opt.param_groups],
+                    "patch_dims": thw}
+        # oracle's own derivation must agree
+        specs = O.derive_specs(mv)
+        for s, bl in zip(specs, blocks):
+            assert (s.dim_in, s.dim_out, s.heads) == (bl["dim_in"], bl["dim_out"], bl["heads"]), (y, s, bl)
+            assert list(s.stride_q) == bl["stride_q"] and list(s.stride_kv) == bl["stride_kv"], (y, s, bl)
+        print("[arith] %s: %d params, %d keys" % (y, table[y]["n_params"], len(sd)))
+    with open(os.path.join(GOLD, "mvit_arith.json"), "w") as f:
+        json.dump(table, f)
+
+
+if __name__ == "__main__":
+    load_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    want = sys.argv[1:]
+    for n in CASES:
+        if not want or any(n.startswith(w) for w in want):
+            run_case(n)
+    if not want or "arith" in want:
+        run_arith()
