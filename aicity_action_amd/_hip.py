@@ -1,0 +1,76 @@
+"""ctypes binding of libmvit_hip.so (the C-ABI in include/mvit_hip.h).
+
+The product path has NO fallback: if the library is missing or a kernel returns an error the
+caller gets an exception.  ``stream`` arguments are raw hipStream_t handles
+(``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvit_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL = 1, 2, 4
+
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+_SIGS = {
+    "mvit_version": (ctypes.c_char_p, []),
+    "mvit_strerror": (ctypes.c_char_p, [c_i]),
+    "mvit_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
+    "mvit_linear_fwd": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_pool_conv_ln_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mvit_maxpool_skip_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_stem_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_head_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "mvit_head_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "mvit_cast_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into lib/libmvit_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mvit_hip.h"))
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    subprocess.check_call(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmvit_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C aicity_action_amd/csrc`. There is no CPU fallback for the HIP path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mvit_strerror(rc).decode()
+        raise RuntimeError("mvit HIP kernel %s failed: %s (code %d)" % (what, msg, rc))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

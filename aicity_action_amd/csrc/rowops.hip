@@ -1,0 +1,281 @@
+// Row-wise, HBM-bound kernels: LayerNorm, final LN + token-mean + head, skip max-pool, casts.
+// All are bandwidth kernels: 16-byte coalesced accesses, no LDS except block reductions.
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm: x fp32 [rows][C] -> y TO [rows][C].  C/12 lanes per row, 3 float4 per lane.
+// Two-pass (mean, then centred variance) in registers, like ATen's CPU kernel.
+// ----------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int C, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TO* __restrict__ y,
+                                                     int64_t rows, float eps) {
+    constexpr int LPR = C / 12;
+    constexpr int RPB = 256 / LPR;
+    const int lir = threadIdx.x % LPR;
+    const int rib = threadIdx.x / LPR;
+    float4 g[3], bt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        g[i] = load4(gamma + 4 * (lir + LPR * i));
+        bt[i] = load4(beta + 4 * (lir + LPR * i));
+    }
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < rows; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t r = r0 + rib;
+        const bool ok = r < rows;
+        float4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            v[i] = ok ? load4(x + r * C + 4 * (lir + LPR * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = group_sum<LPR>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) * (1.0f / C) + eps);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float4 o;
+                o.x = v[i].x * rstd * g[i].x + bt[i].x;
+                o.y = v[i].y * rstd * g[i].y + bt[i].y;
+                o.z = v[i].z * rstd * g[i].z + bt[i].z;
+                o.w = v[i].w * rstd * g[i].w + bt[i].w;
+                store4(y + r * C + 4 * (lir + LPR * i), o);
+            }
+        }
+    }
+}
+
+template <int C>
+static int launch_ln(const float* x, const float* g, const float* b, void* y, int64_t rows, float eps,
+                     int act_dtype, hipStream_t st) {
+    constexpr int RPB = 256 / (C / 12);
+    int64_t blocks = (rows + RPB - 1) / RPB;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (act_dtype == MVIT_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<C, float>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, (float*)y, rows, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<C, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, x, g, b, (bf16_t*)y, rows, eps);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t rows,
+                                  int C, float eps, int act_dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0) return MVIT_EINVAL;
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (rows == 0) return MVIT_OK;
+    hipStream_t st = as_stream(stream);
+    switch (C) {
+        case 96: return launch_ln<96>(x, gamma, beta, y, rows, eps, act_dtype, st);
+        case 192: return launch_ln<192>(x, gamma, beta, y, rows, eps, act_dtype, st);
+        case 384: return launch_ln<384>(x, gamma, beta, y, rows, eps, act_dtype, st);
+        case 768: return launch_ln<768>(x, gamma, beta, y, rows, eps, act_dtype, st);
+        default: return MVIT_EUNSUPPORTED;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Head: final LN + token mean (deterministic two-stage reduction) + Linear + softmax.
+// ----------------------------------------------------------------------------------------------
+#define HEAD_CHUNK 32  // tokens per block of stage 1
+
+template <int C>
+__global__ __launch_bounds__(256) void head_ln_partial_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ part,
+                                                              int N, int nchunks, float eps) {
+    constexpr int LPR = C / 12;
+    constexpr int RPB = 256 / LPR;
+    __shared__ float red[RPB][C];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int lir = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+    float4 g[3], bt[3], acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        g[i] = load4(gamma + 4 * (lir + LPR * i));
+        bt[i] = load4(beta + 4 * (lir + LPR * i));
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int t0 = ch * HEAD_CHUNK;
+    for (int tt = 0; tt < HEAD_CHUNK; tt += RPB) {
+        const int t = t0 + tt + rib;
+        const bool ok = (tt + rib) < HEAD_CHUNK && t < N;
+        float4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            v[i] = ok ? load4(x + ((int64_t)b * N + t) * C + 4 * (lir + LPR * i)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = group_sum<LPR>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) * (1.0f / C) + eps);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                acc[i].x += v[i].x * rstd * g[i].x + bt[i].x;
+                acc[i].y += v[i].y * rstd * g[i].y + bt[i].y;
+                acc[i].z += v[i].z * rstd * g[i].z + bt[i].z;
+                acc[i].w += v[i].w * rstd * g[i].w + bt[i].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(&red[rib][4 * (lir + LPR * i)]) = acc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) s += red[r][c];
+        part[((int64_t)b * nchunks + ch) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_project_kernel(const float* __restrict__ part, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ logits,
+                                                           float* __restrict__ probs, int N, int nchunks, int C, int ncls) {
+    extern __shared__ float sm[];  // z[C] + lg[ncls]
+    float* z = sm;
+    float* lg = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += part[((int64_t)b * nchunks + k) * C + c];
+        z[c] = s / (float)N;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < ncls; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += z[c] * w[(int64_t)j * C + c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) lg[j] = s + bias[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = -INFINITY;
+        for (int j = 0; j < ncls; ++j) m = fmaxf(m, lg[j]);
+        float den = 0.f;
+        for (int j = 0; j < ncls; ++j) den += expf(lg[j] - m);
+        for (int j = 0; j < ncls; ++j) {
+            if (logits) logits[(int64_t)b * ncls + j] = lg[j];
+            if (probs) probs[(int64_t)b * ncls + j] = expf(lg[j] - m) / den;
+        }
+    }
+}
+
+extern "C" int64_t mvit_head_workspace_bytes(int B, int N, int C) {
+    int64_t nchunks = (N + HEAD_CHUNK - 1) / HEAD_CHUNK;
+    return (int64_t)B * nchunks * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mvit_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_head,
+                             const float* b_head, float* workspace, float* logits, float* probs, int B, int N, int C,
+                             int num_classes, float eps, void* stream) {
+    if (!x || !gamma || !beta || !w_head || !b_head || !workspace || B <= 0 || N <= 0 || num_classes <= 0)
+        return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int nchunks = (N + HEAD_CHUNK - 1) / HEAD_CHUNK;
+    dim3 grid(nchunks, B);
+    switch (C) {
+        case 96: hipLaunchKernelGGL((head_ln_partial_kernel<96>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 192: hipLaunchKernelGGL((head_ln_partial_kernel<192>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 384: hipLaunchKernelGGL((head_ln_partial_kernel<384>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 768: hipLaunchKernelGGL((head_ln_partial_kernel<768>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        default: return MVIT_EUNSUPPORTED;
+    }
+    MVIT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_project_kernel, dim3(B), dim3(256), (C + num_classes) * sizeof(float), st, workspace, w_head,
+                       b_head, logits, probs, N, nchunks, C, num_classes);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Skip-path max pool, k(1,3,3) s(1,2,2) p(0,1,1), channel-last fp32.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_skip_kernel(const float* __restrict__ x, float* __restrict__ y, int BT,
+                                                           int H, int W, int Ho, int Wo, int C4) {
+    const int64_t total = (int64_t)BT * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t tok = i / C4;
+        const int xo = (int)(tok % Wo); tok /= Wo;
+        const int yo = (int)(tok % Ho);
+        const int64_t bt = tok / Ho;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yi = 2 * yo + dy - 1;
+            if (yi < 0 || yi >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xi = 2 * xo + dx - 1;
+                if (xi < 0 || xi >= W) continue;
+                const float4 v = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        store4(y + i * 4, m);
+    }
+}
+
+extern "C" int mvit_maxpool_skip_fwd(const float* x, float* y, int B, int T, int H, int W, int C, void* stream) {
+    if (!x || !y || B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MVIT_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)B * T * Ho * Wo * (C / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(maxpool_skip_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, y, B * T, H, W,
+                       Ho, Wo, C / 4);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = f32_to_bf16(s[i]);
+}
+
+extern "C" int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 0) return MVIT_EINVAL;
+    if (n == 0) return MVIT_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, (bf16_t*)dst, n);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1"; }
+
+extern "C" const char* mvit_strerror(int code) {
+    switch (code) {
+        case MVIT_OK: return "ok";
+        case MVIT_EINVAL: return "invalid argument (shape / null pointer)";
+        case MVIT_EDTYPE: return "unsupported dtype";
+        case MVIT_ELAUNCH: return "HIP launch error";
+        case MVIT_EUNSUPPORTED: return "shape outside compiled specialisations";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,60 @@
+"""MODEL_REGISTRY / build_model -- the reference's model factory surface.
+
+Same names, arguments and assertions as slowfast/models/build.py:8-55 so the reference's
+train/test loops (tools/train_net.py:661, tools/test_net.py:203, scripts/module_wrapper.py:466-467)
+can call this factory unchanged.
+"""
+import torch
+
+
+class Registry(object):
+    """Minimal name -> class registry with the fvcore interface the reference uses
+    (``@REG.register()`` decorator and ``REG.get(name)``)."""
+
+    def __init__(self, name):
+        self._name = name
+        self._obj_map = {}
+
+    def _do_register(self, name, obj):
+        assert name not in self._obj_map, "An object named '%s' was already registered in '%s' registry!" % (name, self._name)
+        self._obj_map[name] = obj
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(func_or_class):
+                self._do_register(func_or_class.__name__, func_or_class)
+                return func_or_class
+            return deco
+        self._do_register(obj.__name__, obj)
+
+    def get(self, name):
+        ret = self._obj_map.get(name)
+        if ret is None:
+            raise KeyError("No object named '%s' found in '%s' registry!" % (name, self._name))
+        return ret
+
+    def __contains__(self, name):
+        return name in self._obj_map
+
+
+MODEL_REGISTRY = Registry("MODEL")
+MODEL_REGISTRY.__doc__ = "Registry for video models: the registered object is called as obj(cfg) and returns an nn.Module."
+
+
+def build_model(cfg, gpu_id=None):
+    """Builds the video model named by cfg.MODEL.MODEL_NAME (slowfast/models/build.py:17-55).
+
+    ``torch.cuda`` is the ROCm device API on PyTorch-ROCm; DDP's "nccl" backend is RCCL.
+    """
+    if torch.cuda.is_available():
+        assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
+    else:
+        assert cfg.NUM_GPUS == 0, "Cuda is not available. Please set `NUM_GPUS: 0 for running on CPUs."
+    model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    if cfg.NUM_GPUS:
+        cur_device = torch.cuda.current_device() if gpu_id is None else gpu_id
+        model = model.cuda(device=cur_device)
+    if cfg.NUM_GPUS > 1:
+        model = torch.nn.parallel.DistributedDataParallel(
+            module=model, device_ids=[cur_device], output_device=cur_device)
+    return model

@@ -1,0 +1,311 @@
+"""MViT (MViTv2, conv-pooled multi-scale attention) on hand-written gfx950 HIP kernels.
+
+Drop-in for the reference's ``slowfast.models.video_model_builder.MViT``
+(video_model_builder.py:794-1335): same registry name, same constructor (``MViT(cfg)``), same
+``forward(x, ...)`` contract (``x`` is a list holding one ``[B,3,T,H,W]`` tensor; raw logits in
+``.train()``, softmax in ``.eval()``), same 350 ``state_dict`` keys/shapes (so a reference ``.pyth``
+checkpoint loads and vice versa), same ``no_weight_decay()`` and parameter grouping behaviour.
+
+Sub-modules (nn.Linear / nn.LayerNorm / nn.Conv3d) are used as *parameter containers* only: the
+arithmetic runs in ``aicity_action_amd/csrc`` through the C-ABI of ``include/mvit_hip.h``.
+There is no eager/CPU fallback: calling forward without a gfx950 device or without the built
+library raises.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from .build import MODEL_REGISTRY
+from .spec import derive_block_geoms
+
+
+class _PatchEmbed(nn.Module):
+    """Parameter container matching stem_helper.PatchEmbed (stem_helper.py:308-338): key ``proj``."""
+
+    def __init__(self, dim_in, dim_out, kernel, stride, padding):
+        super().__init__()
+        self.proj = nn.Conv3d(dim_in, dim_out, kernel_size=tuple(kernel), stride=tuple(stride), padding=tuple(padding))
+
+
+class _Mlp(nn.Module):
+    """common.Mlp (common.py:7-34): keys ``fc1``, ``fc2``."""
+
+    def __init__(self, dim, hidden, out):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, out)
+
+
+class _Attention(nn.Module):
+    """attention.MultiScaleAttention (attention.py:86-220): qkv, proj, pool_{q,k,v}, norm_{q,k,v}."""
+
+    def __init__(self, g, qkv_bias):
+        super().__init__()
+        hd = g.head_dim
+        self.qkv = nn.Linear(g.dim_in, g.dim_out * 3, bias=qkv_bias)
+        self.proj = nn.Linear(g.dim_out, g.dim_out)
+
+        def pool(kernel, stride):
+            return nn.Conv3d(hd, hd, tuple(kernel), stride=tuple(stride), padding=tuple(int(k // 2) for k in kernel),
+                             groups=hd, bias=False)
+        if g.kernel_q:
+            self.pool_q = pool(g.kernel_q, g.stride_q)
+            self.norm_q = nn.LayerNorm(hd)          # default eps 1e-5 (attention.py:185 via :338)
+        if g.kernel_kv:
+            self.pool_k = pool(g.kernel_kv, g.stride_kv)
+            self.norm_k = nn.LayerNorm(hd)
+            self.pool_v = pool(g.kernel_kv, g.stride_kv)
+            self.norm_v = nn.LayerNorm(hd)
+
+
+class _Block(nn.Module):
+    """attention.MultiScaleBlock (attention.py:287-410) with CHANNEL_EXPAND_FRONT semantics."""
+
+    def __init__(self, g, qkv_bias, mlp_ratio, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(g.dim_in)
+        self.attn = _Attention(g, qkv_bias)
+        self.norm2 = norm_layer(g.dim_out)
+        self.mlp = _Mlp(g.dim_out, int(g.dim_out * mlp_ratio), g.dim_out)
+        if g.expand:
+            self.proj_max_pool = nn.Linear(g.dim_in, g.dim_out)
+
+
+class _Head(nn.Module):
+    """head_helper.TransformerBasicHead (head_helper.py:369-417): key ``projection``."""
+
+    def __init__(self, dim_in, num_classes):
+        super().__init__()
+        self.projection = nn.Linear(dim_in, num_classes, bias=True)
+
+
+def _unsupported(cond, what):
+    if cond:
+        raise NotImplementedError("MViT (HIP path): %s is not supported" % what)
+
+
+@MODEL_REGISTRY.register()
+class MViT(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.DATA.TRAIN_CROP_SIZE == cfg.DATA.TEST_CROP_SIZE   # video_model_builder.py:805
+        self.cfg = cfg
+        mv = cfg.MVIT
+        _unsupported(mv.CLS_EMBED_ON, "MVIT.CLS_EMBED_ON")
+        _unsupported(not mv.SEP_POS_EMBED, "MVIT.SEP_POS_EMBED False")
+        _unsupported(mv.MODE != "conv", "MVIT.MODE != conv")
+        _unsupported(mv.PATCH_2D, "MVIT.PATCH_2D")
+        _unsupported(not mv.CHANNEL_EXPAND_FRONT, "MVIT.CHANNEL_EXPAND_FRONT False")
+        _unsupported(mv.POOL_SKIP_USE_CONV, "MVIT.POOL_SKIP_USE_CONV")
+        _unsupported(mv.NORM_STEM, "MVIT.NORM_STEM")
+        _unsupported(mv.NO_NORM_BEFORE_AVG, "MVIT.NO_NORM_BEFORE_AVG")
+        _unsupported(mv.DROPOUT_RATE > 0.0, "MVIT.DROPOUT_RATE > 0")
+        _unsupported(cfg.DETECTION.ENABLE, "DETECTION.ENABLE")
+        _unsupported(cfg.MODEL.USE_MULTI_HEAD, "MODEL.USE_MULTI_HEAD")
+        _unsupported(cfg.CONTRA.ENABLE, "CONTRA.ENABLE")
+        _unsupported(cfg.MODEL.ACT_CHECKPOINT, "MODEL.ACT_CHECKPOINT")
+        _unsupported(list(mv.PATCH_KERNEL) != [3, 7, 7] or list(mv.PATCH_STRIDE) != [2, 4, 4]
+                     or list(mv.PATCH_PADDING) != [1, 3, 3], "a patch embed other than k(3,7,7) s(2,4,4) p(1,3,3)")
+        if mv.NORM != "layernorm":
+            raise NotImplementedError("Only supports layernorm.")    # video_model_builder.py:852
+        if cfg.MODEL.HEAD_ACT not in ("softmax",):
+            raise NotImplementedError("{} is not supported as an activation function.".format(cfg.MODEL.HEAD_ACT))
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)                 # video_model_builder.py:848-850
+
+        self.use_query_residual_pool = mv.Q_POOL_RESIDUAL
+        self.direct_input = mv.DIRECT_INPUT
+        self.num_classes = cfg.MODEL.NUM_CLASSES
+        self.head_dropout = cfg.MODEL.DROPOUT_RATE
+        self.use_act_in_train = cfg.MODEL.USE_HEAD_ACT_IN_TRAIN
+        self.input_dims = [cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.TRAIN_CROP_SIZE]
+        self.patch_stride = list(mv.PATCH_STRIDE)
+        self.patch_dims = [self.input_dims[i] // self.patch_stride[i] for i in range(3)]
+
+        geoms, kv_entries = derive_block_geoms(cfg)
+        if mv.POOL_KV_STRIDE_ADAPTIVE is not None:
+            cfg.MVIT.POOL_KV_STRIDE = kv_entries                     # side effect kept (:960-967)
+        for g in geoms:
+            _unsupported(g.head_dim != 96, "head_dim %d (kernels are specialised for 96)" % g.head_dim)
+            _unsupported(bool(g.kernel_q) and tuple(g.kernel_q) != (3, 3, 3), "q pool kernel != 3x3x3")
+            _unsupported(bool(g.kernel_kv) and tuple(g.kernel_kv) != (3, 3, 3), "kv pool kernel != 3x3x3")
+            _unsupported(not g.kernel_q or not g.kernel_kv, "blocks without q/kv pooling conv (Q_POOL_ALL off)")
+            for st in (g.stride_q, g.stride_kv):
+                _unsupported(st[0] != 1 or st[1] != st[2], "pool stride %s" % (st,))
+            _unsupported(g.stride_q[1] not in (1, 2), "q stride %s" % (g.stride_q,))
+        self.geoms = geoms
+
+        embed_dim = mv.EMBED_DIM
+        self.patch_embed = _PatchEmbed(cfg.DATA.INPUT_CHANNEL_NUM[0], embed_dim, mv.PATCH_KERNEL, mv.PATCH_STRIDE,
+                                       mv.PATCH_PADDING)
+        self.pos_embed_spatial = nn.Parameter(torch.zeros(1, self.patch_dims[1] * self.patch_dims[2], embed_dim))
+        self.pos_embed_temporal = nn.Parameter(torch.zeros(1, self.patch_dims[0], embed_dim))
+        self.blocks = nn.ModuleList([_Block(g, mv.QKV_BIAS, mv.MLP_RATIO, norm_layer) for g in geoms])
+        self.norm = norm_layer(geoms[-1].dim_out)
+        nn.init.trunc_normal_(self.pos_embed_spatial, std=0.02)      # :1046-1049
+        nn.init.trunc_normal_(self.pos_embed_temporal, std=0.02)
+        self.head = _Head(geoms[-1].dim_out, self.num_classes)
+        self.apply(self._init_weights)                               # :1119
+        self._bf16_cache = {}
+
+    @staticmethod
+    def _init_weights(m):                                            # :1126-1133
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):                                       # :1135-1159
+        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:
+            return {"pos_embed_spatial", "pos_embed_temporal", "pos_embed_class"}
+        return {}
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def precision(self):
+        hip = getattr(self.cfg, "HIP", None)
+        p = getattr(hip, "PRECISION", "bf16") if hip is not None else "bf16"
+        if p not in ("bf16", "fp32"):
+            raise ValueError("cfg.HIP.PRECISION must be 'bf16' or 'fp32', got %r" % (p,))
+        return p
+
+    def _w(self, param, act):
+        """Weight in the activation dtype of the MFMA path (fp32 master -> cached bf16 copy)."""
+        if act == _hip.F32:
+            return param
+        key = id(param)
+        ent = self._bf16_cache.get(key)
+        if ent is None or ent[0] != param._version or ent[1].device != param.device:
+            buf = torch.empty(param.shape, dtype=torch.bfloat16, device=param.device)
+            st = torch.cuda.current_stream().cuda_stream
+            _hip.check(_hip.lib().mvit_cast_f32_to_bf16(_hip.ptr(param), _hip.ptr(buf), param.numel(), st), "cast")
+            ent = (param._version, buf)
+            self._bf16_cache[key] = ent
+        return ent[1]
+
+    def forward(self, x, bboxes=None, dataset_name=None, run_cross_proj=False, use_moco=False, moco_momentum=0.9,
+                return_logits=False):
+        if not self.direct_input:
+            x = x[0]                                                 # :1165-1167
+        if not x.is_cuda:
+            raise RuntimeError("MViT (HIP path) needs its input on a gfx950 device; there is no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..autograd import forward_with_grad
+            return forward_with_grad(self, x, return_logits)
+        return self._forward_hip(x, return_logits)
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_hip(self, clip, return_logits=False, taps=None):
+        L = _hip.lib()
+        dev = clip.device
+        st = torch.cuda.current_stream().cuda_stream
+        act = _hip.BF16 if self.precision == "bf16" else _hip.F32
+        adt = torch.bfloat16 if act == _hip.BF16 else torch.float32
+        clip = clip.contiguous().float()
+        B, Cin, T, S, S2 = clip.shape
+        assert Cin == 3 and S == S2 and [T, S, S] == self.input_dims, "clip shape %s != configured %s" % (
+            tuple(clip.shape), self.input_dims)
+        Tp, Hp, Wp = self.patch_dims
+        N = Tp * Hp * Wp
+        x = torch.empty(B, N, 96, dtype=torch.float32, device=dev)
+        pe = self.patch_embed.proj
+        _hip.check(L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(pe.weight), _hip.ptr(pe.bias),
+                                   _hip.ptr(self.pos_embed_spatial), _hip.ptr(self.pos_embed_temporal), _hip.ptr(x),
+                                   B, T, S, act, st), "stem")
+        if taps is not None:
+            taps["stem"] = x
+        for g, blk in zip(self.geoms, self.blocks):
+            x = self._block_fwd(L, st, act, adt, g, blk, x, B, taps)
+            if taps is not None:
+                taps["block%d" % g.index] = x
+        C = self.geoms[-1].dim_out
+        Nf = x.shape[1]
+        ws = torch.empty(L.mvit_head_workspace_bytes(B, Nf, C) // 4, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=dev)
+        probs = torch.empty(B, self.num_classes, dtype=torch.float32, device=dev)
+        hp = self.head.projection
+        _hip.check(L.mvit_head_fwd(_hip.ptr(x), _hip.ptr(self.norm.weight), _hip.ptr(self.norm.bias), _hip.ptr(hp.weight),
+                                   _hip.ptr(hp.bias), _hip.ptr(ws), _hip.ptr(logits), _hip.ptr(probs), B, Nf, C,
+                                   self.num_classes, self.norm.eps, st), "head")
+        if return_logits:
+            return probs, logits
+        if self.training and not self.use_act_in_train:
+            return logits
+        return probs
+
+    def _linear(self, L, st, act, a, a_dt, lin, out_dtype, M, residual=None, gelu=False, w=None, b=None):
+        weight = lin.weight if w is None else w
+        bias = lin.bias if b is None else b
+        N, K = weight.shape
+        y = torch.empty(M, N, dtype=out_dtype, device=a.device)
+        epi = (_hip.EPI_BIAS if bias is not None else 0) | (_hip.EPI_GELU if gelu else 0) | (
+            _hip.EPI_RESIDUAL if residual is not None else 0)
+        odt = _hip.BF16 if out_dtype == torch.bfloat16 else _hip.F32
+        _hip.check(L.mvit_linear_fwd(_hip.ptr(a), a_dt, K, _hip.ptr(self._w(weight, act)), _hip.ptr(bias),
+                                     _hip.ptr(residual), N, None, 0, _hip.ptr(y), odt, N, M, N, K, epi, act, st),
+                   "linear %dx%dx%d" % (M, N, K))
+        return y
+
+    def _block_fwd(self, L, st, act, adt, g, blk, x, B, taps=None):
+        dev = x.device
+        T, H, W = g.thw_in
+        N = g.n_in
+        M = B * N
+        Cin, Cout, h = g.dim_in, g.dim_out, g.heads
+        at = blk.attn
+        # 1. U = LN1(x)                                                   attention.py:421
+        u = torch.empty(M, Cin, dtype=adt, device=dev)
+        _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
+                                        Cin, blk.norm1.eps, act, st), "norm1")
+        # 2. fused qkv projection, kept token-major [B,N,3*Cout]          attention.py:230-236
+        qkv = self._linear(L, st, act, u, act, at.qkv, adt, M)
+        del u
+        # 3. pooling conv + LN of q, k, v straight from the fused buffer   attention.py:241-261
+        Tq, Hq, Wq = g.thw_q
+        Tk, Hk, Wk = g.thw_kv
+        Lq, Lk = g.lq, g.lk
+        q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
+        k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
+        v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
+        for which, (buf, conv, norm, stride) in enumerate(((q, at.pool_q, at.norm_q, g.stride_q[1]),
+                                                           (k, at.pool_k, at.norm_k, g.stride_kv[1]),
+                                                           (v, at.pool_v, at.norm_v, g.stride_kv[1]))):
+            _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight),
+                                               _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W,
+                                               stride, norm.eps, act, st), "pool%d" % which)
+        del qkv
+        # 4. fused attention (+ pooled-q residual), heads merged on store   attention.py:267-279
+        o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
+        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), B, h, Lq, Lk,
+                                        96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st), "attention")
+        if taps is not None:
+            taps["block%d.q" % g.index] = q
+            taps["block%d.k" % g.index] = k
+            taps["block%d.v" % g.index] = v
+            taps["block%d.attn_out" % g.index] = o.view(B, Lq, Cout)
+        del q, k, v
+        # 5. skip path: channel expand on the un-normed x, then max-pool     attention.py:424-432
+        r = x.view(M, Cin)
+        if g.expand:
+            r = self._linear(L, st, act, r, _hip.F32, blk.proj_max_pool, torch.float32, M)
+        if not g.skip_is_identity:
+            rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r), _hip.ptr(rp), B, T, H, W, Cout, st), "maxpool")
+            r = rp
+        # 6. y = r + proj(o)                                                 attention.py:281,434
+        y = self._linear(L, st, act, o, act, at.proj, torch.float32, B * Lq, residual=r)
+        del o, r
+        # 7-9. x_out = y + fc2(gelu(fc1(LN2(y))))                            attention.py:436-445
+        vn = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
+        _hip.check(L.mvit_layernorm_fwd(_hip.ptr(y), _hip.ptr(blk.norm2.weight), _hip.ptr(blk.norm2.bias), _hip.ptr(vn),
+                                        B * Lq, Cout, blk.norm2.eps, act, st), "norm2")
+        hid = self._linear(L, st, act, vn, act, blk.mlp.fc1, adt, B * Lq, gelu=True)
+        del vn
+        out = self._linear(L, st, act, hid, act, blk.mlp.fc2, torch.float32, B * Lq, residual=y)
+        return out.view(B, Lq, Cout)

@@ -1,0 +1,112 @@
+/*
+ * mvit_hip.h -- C-ABI of the MI355X (gfx950) MViTv2 hot path.
+ *
+ * The reference (JunweiLiang/aicity_action) is pure Python: it has no FFI of its own; every
+ * operator below replaces an implicit ATen dispatch on the MViT path, cited per entry point as
+ * reference file:line (paths relative to the reference root).  The host side
+ * (aicity_action_amd/, Python on PyTorch-ROCm) binds this library with ctypes -- see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions ("C-ABI layer"):
+ *   - plain pointers + sizes; all pointers are DEVICE pointers owned by the caller;
+ *   - the library never allocates, never synchronises, never throws;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *     0 (MVIT_OK) or a negative MVIT_E* code;
+ *   - token-major activations: [batch][token][channel], channel contiguous;
+ *   - `act_dtype`: MVIT_F32 or MVIT_BF16 = storage type of intermediate activations (and
+ *     the MFMA operand type); the residual stream and all parameters are always fp32 unless a
+ *     parameter is documented as "act-typed" (pre-converted by the host at load time).
+ */
+#ifndef MVIT_HIP_H
+#define MVIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MVIT_F32 = 0, MVIT_BF16 = 1 };
+
+enum {
+    MVIT_OK = 0,
+    MVIT_EINVAL = -1,      /* bad shape / null pointer */
+    MVIT_EDTYPE = -2,      /* unsupported dtype combination */
+    MVIT_ELAUNCH = -3,     /* hipGetLastError() != hipSuccess after a launch */
+    MVIT_EUNSUPPORTED = -4 /* shape outside the compiled specialisations (e.g. head_dim != 96) */
+};
+
+/* GEMM epilogue flags */
+enum {
+    MVIT_EPI_BIAS = 1,     /* + bias[n] (fp32) */
+    MVIT_EPI_GELU = 2,     /* exact erf GELU after bias (reference slowfast/models/common.py:28) */
+    MVIT_EPI_RESIDUAL = 4  /* + residual[m][n] (fp32), applied last */
+};
+
+const char* mvit_version(void);
+const char* mvit_strerror(int code);
+
+/* LayerNorm over the last dim, biased variance, affine; x fp32 [rows][C] -> y act-typed [rows][C].
+ * Replaces nn.LayerNorm at slowfast/models/attention.py:421,436 (eps 1e-6) and
+ * slowfast/models/video_model_builder.py:1248-1249.  C in {96,192,384,768}. */
+int mvit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                       int64_t rows, int C, float eps, int act_dtype, void* stream);
+
+/* y[M][N] = epilogue( a[M][K] . w[N][K]^T ).  Replaces nn.Linear (addmm) at
+ * slowfast/models/attention.py:231 (qkv), :281 (proj), :426 (proj_max_pool),
+ * slowfast/models/common.py:27-31 (fc1/fc2).
+ *   a:  a_dtype-typed (MVIT_F32 or MVIT_BF16), row stride lda elements
+ *   w:  act-typed [N][K] (host pre-converts fp32 parameters when act_dtype == MVIT_BF16)
+ *   bias fp32 [N] or NULL; residual fp32 [M][N] (row stride ldr) or NULL
+ *   row_scale: NULL, or fp32 [M / rows_per_scale]: drop-path factor per sample applied to
+ *              (acc + bias) before the residual add (slowfast/models/common.py:46-59)
+ *   y:  out_dtype-typed, row stride ldy.
+ * Constraints: K % 96 == 0 or K % 32 == 0; N % 32 == 0 for the bf16 MFMA path. */
+int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const void* w, const float* bias,
+                    const float* residual, int64_t ldr, const float* row_scale, int64_t rows_per_scale,
+                    void* y, int out_dtype, int64_t ldy, int64_t M, int N, int K, int epilogue,
+                    int act_dtype, void* stream);
+
+/* Pooling conv + LayerNorm of one of q/k/v for all heads (attention_pool, conv variant:
+ * slowfast/models/attention.py:12-83 with the Conv3d of :172-212 and LayerNorm(eps 1e-5) of
+ * :185,199,213).  Input is the fused qkv activation [B][T*H*W][ld] (act-typed); channel of
+ * (which, head g, d) = chan_off + g*96 + d.  Depthwise 3x3x3, zero pad 1, stride (1,s,s), the same
+ * w[96][27] (fp32, reference layout [96,1,3,3,3]) for every head.  Output [B][heads][T*Ho*Wo][96]
+ * act-typed.  head_dim is fixed at 96 (every block of every configs/Aicity model). */
+int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                          const float* beta, void* out, int B, int heads, int T, int H, int W,
+                          int stride_hw, float eps, int act_dtype, void* stream);
+
+/* out[b][lq][g*96+d] = softmax_k(q.k^T * scale) . v (+ q if add_q)  -- fused, scores never stored.
+ * Replaces bmm/softmax/bmm + residual at slowfast/models/attention.py:267-279.
+ * q [B][heads][Lq][96], k,v [B][heads][Lk][96], out [B][Lq][heads*96], all act-typed. */
+int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int heads,
+                       int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
+
+/* Skip-path MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) on the token grid (slowfast/models/attention.py:
+ * 316-318,389-395,427-432); x fp32 [B][T*H*W][C] -> y fp32 [B][T*Ho*Wo][C]. */
+int mvit_maxpool_skip_fwd(const float* x, float* y, int B, int T, int H, int W, int C, void* stream);
+
+/* Cube embedding + separable position embedding (slowfast/models/stem_helper.py:335-338,
+ * slowfast/models/video_model_builder.py:1196-1223): Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) +
+ * bias, output token-major, + pos_spatial[h*W'+w] + pos_temporal[t].
+ * clip fp32 [B][3][T][S][S]; w fp32 [96][3][3][7][7]; x fp32 [B][T/2*S/4*S/4][96]. */
+int mvit_stem_fwd(const float* clip, const float* w, const float* bias, const float* pos_spatial,
+                  const float* pos_temporal, float* x, int B, int T, int S, int act_dtype, void* stream);
+
+/* Final LayerNorm(eps) + token mean + Linear(C,num_classes) + optional softmax
+ * (slowfast/models/video_model_builder.py:1248-1249,1310; slowfast/models/head_helper.py:409-417).
+ * x fp32 [B][N][C]; workspace fp32, at least mvit_head_workspace_bytes(B,N,C) bytes;
+ * logits/probs fp32 [B][num_classes] (either may be NULL). */
+int64_t mvit_head_workspace_bytes(int B, int N, int C);
+int mvit_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_head,
+                  const float* b_head, float* workspace, float* logits, float* probs, int B, int N,
+                  int C, int num_classes, float eps, void* stream);
+
+/* fp32 -> bf16 (round to nearest even) conversion of parameters, n elements. */
+int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVIT_HIP_H */

@@ -1,0 +1,209 @@
+"""GPU: every C-ABI operator against the oracle's op (same seeded inputs), fp32 (exact path) and bf16 (MFMA path).
+
+fp32 tolerance: 1e-5 relative-to-scale (summation order differs from ATen).  bf16 tolerance: inputs are rounded to
+bf16 first so the reference sees the same operands; remaining error is bf16 rounding of outputs / P (2^-8 rel).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mvit_oracle as O
+from aicity_action_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _act(t, act):
+    return t.to(torch.bfloat16) if act == _hip.BF16 else t.float()
+
+
+def _tol(act, fp32=2e-5, bf16=2e-2):
+    return bf16 if act == _hip.BF16 else fp32
+
+
+def _close(got, ref, tol):
+    got = got.float().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "max err %.3e > %.3e (scale %.3f)" % (err, tol * scale, scale)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("C,rows", [(96, 1000), (192, 37), (384, 392), (768, 65)])
+def test_layernorm(hip_lib, act, C, rows):
+    x = _rnd(rows, C, seed=1) * 2 + 0.5
+    g, b = 1 + 0.1 * _rnd(C, seed=2), 0.1 * _rnd(C, seed=3)
+    ref = F.layer_norm(x, (C,), g, b, 1e-6)
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    y = torch.empty(rows, C, dtype=torch.bfloat16 if act else torch.float32, device=DEV)
+    _hip.check(hip_lib.mvit_layernorm_fwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(y), rows, C, 1e-6, act, _st()))
+    _close(y, ref, _tol(act, bf16=8e-3))
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("M,N,K,epi", [(392, 288, 96, "b"), (1000, 96, 384, "br"), (129, 384, 96, "bg"),
+                                        (64, 192, 768, "b"), (257, 96, 96, ""), (512, 576, 192, "brg")])
+def test_linear(hip_lib, act, M, N, K, epi):
+    a = _act(_rnd(M, K, seed=4), act)
+    w = _act(_rnd(N, K, seed=5, scale=0.05), act)
+    bias = _rnd(N, seed=6, scale=0.1)
+    res = _rnd(M, N, seed=7)
+    ref = a.float() @ w.float().t()
+    flags = 0
+    if "b" in epi:
+        ref = ref + bias
+        flags |= _hip.EPI_BIAS
+    if "g" in epi:
+        ref = F.gelu(ref)
+        flags |= _hip.EPI_GELU
+    if "r" in epi:
+        ref = ref + res
+        flags |= _hip.EPI_RESIDUAL
+    for out_bf16 in ([False, True] if act == _hip.BF16 else [False]):
+        y = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=DEV)
+        ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+        _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(ad), act, K, _hip.ptr(wd), _hip.ptr(bd) if "b" in epi else None,
+                                           _hip.ptr(rd) if "r" in epi else None, N, None, 0, _hip.ptr(y),
+                                           _hip.BF16 if out_bf16 else _hip.F32, N, M, N, K, flags, act, _st()))
+        _close(y, ref, 1e-2 if out_bf16 else (2e-3 if act else 2e-5))
+
+
+def test_linear_bf16_with_fp32_a_and_row_scale(hip_lib):
+    M, N, K = 300, 192, 96
+    a = _rnd(M, K, seed=8)
+    w = _rnd(N, K, seed=9, scale=0.05).to(torch.bfloat16)
+    bias = _rnd(N, seed=10, scale=0.1)
+    res = _rnd(M, N, seed=11)
+    scale = torch.tensor([0.0, 1.25, 2.0])
+    ref = (a.to(torch.bfloat16).float() @ w.float().t() + bias) * scale.repeat_interleave(100)[:, None] + res
+    y = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ad, wd, bd, rd, sd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), scale.to(DEV)
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(ad), _hip.F32, K, _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(rd), N,
+                                       _hip.ptr(sd), 100, _hip.ptr(y), _hip.F32, N, M, N, K,
+                                       _hip.EPI_BIAS | _hip.EPI_RESIDUAL, _hip.BF16, _st()))
+    _close(y, ref, 2e-3)
+
+
+def test_linear_rejects_bad_shapes(hip_lib):
+    t = torch.zeros(64, 64, device=DEV)
+    assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
+                                   64, 64, 64, 64, 0, _hip.BF16, _st()) == -4
+    assert hip_lib.mvit_linear_fwd(None, _hip.F32, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.F32, 64, 64,
+                                   64, 64, 0, _hip.F32, _st()) == -1
+    assert hip_lib.mvit_layernorm_fwd(_hip.ptr(t), _hip.ptr(t), _hip.ptr(t), _hip.ptr(t), 64, 100, 1e-6, 0, _st()) == -4
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,h,T,H,W,s", [(2, 1, 2, 16, 16, 1), (1, 2, 2, 14, 14, 2), (2, 2, 3, 7, 7, 2),
+                                         (1, 4, 2, 14, 14, 4), (1, 1, 8, 28, 28, 8), (1, 2, 2, 5, 9, 1)])
+def test_pool_conv_ln(hip_lib, act, B, h, T, H, W, s):
+    C = 96 * h
+    N = T * H * W
+    qkv = _act(_rnd(B, N, 3 * C, seed=12), act)
+    w = _rnd(96, 1, 3, 3, 3, seed=13, scale=0.3)
+    g, b = 1 + 0.1 * _rnd(96, seed=14), 0.1 * _rnd(96, seed=15)
+    for which in range(3):
+        x = qkv.float()[:, :, which * C:(which + 1) * C].reshape(B, N, h, 96).permute(0, 2, 1, 3)
+        ref, thw = O._pool_conv_ln(x, (T, H, W), w, (1, s, s), g, b)
+        Lo = thw[0] * thw[1] * thw[2]
+        out = torch.empty(B, h, Lo, 96, dtype=qkv.dtype, device=DEV)
+        qd, wd, gd, bd = qkv.to(DEV), w.to(DEV), g.to(DEV), b.to(DEV)
+        _hip.check(hip_lib.mvit_pool_conv_ln_fwd(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd),
+                                                 _hip.ptr(out), B, h, T, H, W, s, 1e-5, act, _st()))
+        _close(out, ref, _tol(act, fp32=2e-5, bf16=1e-2))
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(1, 1, 128, 64, 1), (2, 2, 392, 392, 1), (1, 4, 100, 33, 0),
+                                               (1, 1, 1568, 1568, 1), (2, 8, 49, 200, 1), (1, 2, 257, 6272, 1)])
+def test_attention(hip_lib, act, B, h, Lq, Lk, add_q):
+    q = _act(_rnd(B, h, Lq, 96, seed=16), act)
+    k = _act(_rnd(B, h, Lk, 96, seed=17), act)
+    v = _act(_rnd(B, h, Lk, 96, seed=18), act)
+    scale = 96 ** -0.5
+    p = ((q.float() @ k.float().transpose(-2, -1)) * scale).softmax(-1)
+    ref = p @ v.float()
+    if add_q:
+        ref = ref + q.float()
+    ref = ref.transpose(1, 2).reshape(B, Lq, h * 96)
+    out = torch.empty(B, Lq, h * 96, dtype=q.dtype, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), B, h, Lq, Lk, scale,
+                                          add_q, act, _st()))
+    _close(out, ref, _tol(act, fp32=2e-5, bf16=1e-2))
+
+
+def test_attention_bf16_online_softmax_rescale_is_exercised(hip_lib):
+    """A key with a much larger score late in the sequence forces the running-max rescale branch."""
+    B, h, Lq, Lk = 1, 1, 64, 256
+    q = _rnd(B, h, Lq, 96, seed=19)
+    k = _rnd(B, h, Lk, 96, seed=20)
+    v = _rnd(B, h, Lk, 96, seed=21)
+    k[0, 0, 200] = q[0, 0, 5] * 3.0    # spike: q5.k200 is huge, appears in the 4th tile
+    k[0, 0, 70] = q[0, 0, 9] * 2.0
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    scale = 96 ** -0.5
+    ref = (((q.float() @ k.float().transpose(-2, -1)) * scale).softmax(-1) @ v.float()).transpose(1, 2).reshape(B, Lq, 96)
+    out = torch.empty(B, Lq, 96, dtype=torch.bfloat16, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), B, h, Lq, Lk, scale, 0,
+                                          _hip.BF16, _st()))
+    _close(out, ref, 1e-2)
+
+
+@pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 2, 14, 14, 768), (1, 1, 5, 9, 96)])
+def test_maxpool_skip(hip_lib, B, T, H, W, C):
+    x = _rnd(B, T * H * W, C, seed=22)
+    t = x.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+    ref = F.max_pool3d(t, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    Lo = ref.shape[2] * ref.shape[3] * ref.shape[4]
+    ref = ref.reshape(B, C, Lo).transpose(1, 2)
+    y = torch.empty(B, Lo, C, device=DEV)
+    xd = x.to(DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_fwd(_hip.ptr(xd), _hip.ptr(y), B, T, H, W, C, _st()))
+    assert torch.equal(y.cpu(), ref.contiguous())   # pure selection: bit-exact
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 16, 224)])
+def test_stem(hip_lib, act, B, T, S):
+    clip = _rnd(B, 3, T, S, S, seed=23)
+    w = _rnd(96, 3, 3, 7, 7, seed=24, scale=0.05)
+    bias = _rnd(96, seed=25, scale=0.05)
+    To, So = T // 2, S // 4
+    ps, pt = _rnd(1, So * So, 96, seed=26, scale=0.02), _rnd(1, To, 96, seed=27, scale=0.02)
+    ref = F.conv3d(clip, w, bias, stride=(2, 4, 4), padding=(1, 3, 3)).flatten(2).transpose(1, 2)
+    ref = ref + (ps.repeat(1, To, 1) + torch.repeat_interleave(pt, So * So, dim=1))
+    x = torch.empty(B, To * So * So, 96, device=DEV)
+    args = [t.to(DEV) for t in (clip, w, bias, ps, pt)]
+    _hip.check(hip_lib.mvit_stem_fwd(*[_hip.ptr(t) for t in args], _hip.ptr(x), B, T, S, act, _st()))
+    _close(x, ref, _tol(act, fp32=2e-5, bf16=5e-3))
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 392, 768), (3, 32, 384), (1, 1568, 768), (2, 50, 96)])
+def test_head(hip_lib, B, N, C):
+    x = _rnd(B, N, C, seed=28) + 0.3
+    g, b = 1 + 0.1 * _rnd(C, seed=29), 0.1 * _rnd(C, seed=30)
+    w, hb = _rnd(18, C, seed=31, scale=0.05), _rnd(18, seed=32, scale=0.1)
+    z = F.layer_norm(x, (C,), g, b, 1e-6).mean(1)
+    ref_logits = F.linear(z, w, hb)
+    ws = torch.empty(hip_lib.mvit_head_workspace_bytes(B, N, C) // 4, device=DEV)
+    logits = torch.empty(B, 18, device=DEV)
+    probs = torch.empty(B, 18, device=DEV)
+    args = [t.to(DEV) for t in (x, g, b, w, hb)]
+    _hip.check(hip_lib.mvit_head_fwd(*[_hip.ptr(t) for t in args], _hip.ptr(ws), _hip.ptr(logits), _hip.ptr(probs), B, N, C,
+                                     18, 1e-6, _st()))
+    _close(logits, ref_logits, 1e-5)
+    _close(probs, ref_logits.softmax(1), 1e-5)

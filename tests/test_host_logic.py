@@ -1,0 +1,125 @@
+"""CPU: host-side logic -- cfg loading, block geometry vs the reference-derived table, state_dict layout,
+optimizer grouping, registry/build_model semantics, C-ABI exports."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLD, ROOT
+
+from aicity_action_amd import _hip
+from aicity_action_amd.config import load_config
+from aicity_action_amd.models import MODEL_REGISTRY, MViT, build_model
+from aicity_action_amd.models.spec import derive_block_geoms
+
+ARITH = json.load(open(os.path.join(GOLD, "mvit_arith.json")))
+OURS = [y for y in ARITH if os.path.exists(os.path.join(ROOT, "configs", "Aicity", y))]
+
+
+def _cfg(y):
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", y))
+    cfg.NUM_GPUS = 0
+    return cfg
+
+
+@pytest.mark.parametrize("y", OURS)
+def test_block_geometry_matches_reference(y):
+    cfg = _cfg(y)
+    geoms, kv = derive_block_geoms(cfg)
+    ref = ARITH[y]
+    assert len(geoms) == len(ref["blocks"])
+    assert [list(map(int, e)) for e in kv] == ref["pool_kv_stride"]
+    for g, r in zip(geoms, ref["blocks"]):
+        assert (g.dim_in, g.dim_out, g.heads) == (r["dim_in"], r["dim_out"], r["heads"])
+        assert list(g.stride_q) == r["stride_q"] and list(g.stride_kv) == r["stride_kv"]
+        assert g.expand == r["has_pmp"]
+        assert abs(g.drop_path - r["drop_path"]) < 1e-7
+        if r["skip"] is None:
+            assert g.skip_kernel is None
+        else:
+            assert [list(g.skip_kernel), list(g.skip_stride), list(g.skip_pad)] == r["skip"]
+    assert list(geoms[0].thw_in) == ref["patch_dims"]
+
+
+@pytest.mark.parametrize("y", [y for y in OURS if "16x4" in y])
+def test_state_dict_layout_and_param_groups(y):
+    cfg = _cfg(y)
+    model = build_model(cfg)
+    ref = ARITH[y]
+    sd = model.state_dict()
+    assert list(sd.keys()) == ref["keys"]
+    assert [list(v.shape) for v in sd.values()] == ref["shapes"]
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    assert sum(p.numel() for p in model.parameters()) == ref["n_params"]
+    assert model.no_weight_decay() == {}
+    # the reference's grouping rule (slowfast/models/optimizer.py:56-75, ZERO_WD_1D_PARAM): 1-D -> no decay
+    wd = [p for m in model.modules() for p in m.parameters(recurse=False) if p.ndim > 1]
+    nwd = [p for m in model.modules() for p in m.parameters(recurse=False) if p.ndim == 1]
+    sizes = dict(zip(ref["group_wd"], ref["group_sizes"]))
+    assert len(wd) == sizes[cfg.SOLVER.WEIGHT_DECAY] and len(nwd) == sizes[0.0]
+    # construction mutates cfg.MVIT.POOL_KV_STRIDE like the reference (video_model_builder.py:960-967)
+    assert [list(map(int, e)) for e in cfg.MVIT.POOL_KV_STRIDE] == ref["pool_kv_stride"]
+
+
+def test_registry_and_build_model_contract():
+    assert MODEL_REGISTRY.get("MViT") is MViT
+    with pytest.raises(KeyError):
+        MODEL_REGISTRY.get("SlowFast")
+    cfg = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
+    if not torch.cuda.is_available():
+        cfg.NUM_GPUS = 1
+        with pytest.raises(AssertionError):
+            build_model(cfg)      # slowfast/models/build.py:29-32
+        cfg.NUM_GPUS = 0
+    m = build_model(cfg)
+    # product path has no CPU fallback
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m([torch.zeros(1, 3, 16, 224, 224)])
+
+
+def test_cfg_cli_overrides_and_unsupported_branches():
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"),
+                      ["NUM_GPUS", "0", "SOLVER.BASE_LR", "1e-4", "MVIT.POOL_Q_STRIDE", "[[1, 1, 2, 2]]",
+                       "TRAIN.MIXED_PRECISION", "False", "MODEL.LOSS_FUNC", "cross_entropy"])
+    assert cfg.NUM_GPUS == 0 and cfg.SOLVER.BASE_LR == 1e-4 and cfg.MVIT.POOL_Q_STRIDE == [[1, 1, 2, 2]]
+    assert cfg.TRAIN.MIXED_PRECISION is False and cfg.MODEL.LOSS_FUNC == "cross_entropy"
+    assert cfg.SOLVER.WEIGHT_DECAY == 1e-4 and isinstance(cfg.dump(), str)
+    cfg2 = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
+    cfg2.MVIT.CLS_EMBED_ON = True
+    with pytest.raises(NotImplementedError):
+        MViT(cfg2)
+    cfg3 = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
+    cfg3.DATA.TEST_CROP_SIZE = 256
+    with pytest.raises(AssertionError):
+        MViT(cfg3)
+
+
+def test_checkpoint_roundtrip_pyth_layout(tmp_path):
+    """.pyth dict layout of slowfast/utils/checkpoint.py:127-134 round-trips through load_state_dict."""
+    cfg = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
+    m = build_model(cfg)
+    ck = {"epoch": 3, "model_state": m.state_dict(), "optimizer_state": {}, "cfg": cfg.dump()}
+    p = tmp_path / "checkpoint_epoch_00004.pyth"
+    torch.save(ck, str(p))
+    m2 = build_model(_cfg("MVITV2_FULL_B_16x4_CONV.yaml"))
+    missing, unexpected = m2.load_state_dict(torch.load(str(p), map_location="cpu")["model_state"], strict=False)
+    assert not missing and not unexpected
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_capi_library_builds_and_exports_every_declared_symbol():
+    path = _hip.build()
+    L = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "mvit_hip.h")).read()
+    declared = set(re.findall(r"\b(mvit_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no entry points parsed from include/mvit_hip.h"
+    for name in declared:
+        assert hasattr(L, name), "libmvit_hip.so does not export %s" % name
+    assert declared == set(_hip.EXPORTS), (declared ^ set(_hip.EXPORTS))
+    assert _hip.lib().mvit_version().decode().startswith("mvit-hip")
+    assert _hip.lib().mvit_strerror(-4).decode()

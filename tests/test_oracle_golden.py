@@ -1,0 +1,72 @@
+"""CPU: the oracle (oracle/mvit_oracle.py) against the committed golden vectors that were produced by
+the real reference (oracle/make_golden.py). Runs anywhere, no reference needed."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import cfg_for_case, load_golden, sample_like
+
+import mvit_oracle as O
+from aicity_action_amd.utils.synth import synth_clip, synth_state_dict
+
+
+def _mv(cfg):
+    return copy.deepcopy(cfg.MVIT.to_dict())
+
+
+def _run(name, train=False):
+    z, meta = load_golden(name)
+    cfg = cfg_for_case(meta, train=train)
+    sd = synth_state_dict(dict(zip(meta["state_keys"], meta["state_shapes"])), meta["weight_seed"])
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"])
+    return z, meta, cfg, sd, clip
+
+
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "full224"])
+def test_oracle_forward_matches_reference_golden(name):
+    z, meta, cfg, sd, clip = _run(name)
+    taps = {}
+    with torch.no_grad():
+        probs, logits = O.forward(sd, clip, _mv(cfg), taps=taps)
+    assert np.abs(logits.numpy() - z["logits"]).max() <= 1e-5
+    assert np.abs(probs.numpy() - z["probs"]).max() <= 1e-5
+    for k in [k for k in z.files if k.startswith("tap.")]:
+        got = sample_like(taps[k[4:]], z["mom." + k[4:]])
+        ref = z[k]
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), k
+    for k in [k for k in z.files if k.startswith("thw")]:
+        assert list(taps[k]) == list(z[k])
+
+
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd"])
+def test_oracle_train_step_matches_reference_golden(name):
+    z, meta, cfg, sd, clip = _run(name, train=True)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    labels = torch.from_numpy(z["train.labels"])
+    out, _ = O.forward(sd, clip, _mv(cfg), training=True)
+    loss = O.soft_target_cross_entropy(out, labels)
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) <= 1e-6
+    assert np.abs(out.detach().numpy() - z["train.logits"]).max() <= 1e-5
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values())).item()
+    assert abs(tot - float(z["train.grad_norm"])) <= 1e-5 * max(1.0, tot)
+    coef = min(1.0, meta["clip"] / (tot + 1e-6))          # torch clip_grad_norm_ semantics
+    lr = O.lr_at_epoch(meta["solver"], 0.25)
+    assert abs(lr - float(z["train.lr"])) < 1e-12
+    wd_names = set(meta["wd_group"])
+    assert len(meta["wd_group"]) + len(meta["no_wd_group"]) == len(sd)
+    for k, v in sd.items():
+        gref = z["grad." + k]
+        g = v.grad * coef
+        got = sample_like(g, z["gmom." + k])
+        assert np.abs(got - gref).max() <= 1e-5 * max(1.0, np.abs(gref).max()) + 1e-7, k
+        # one AdamW step (decoupled weight decay, bias-corrected, eps 1e-8), step 1
+        wd = meta["weight_decay"] if k in wd_names else 0.0
+        p = v.detach() * (1 - lr * wd)
+        m = 0.1 * g
+        s = 0.001 * g * g
+        p = p - lr * (m / 0.1) / ((s / 0.001).sqrt() + 1e-8)
+        got = sample_like(p, z["gmom." + k])
+        assert np.abs(got - z["step." + k]).max() <= 2e-6, k
