@@ -113,26 +113,35 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax (log2 domain) ------------------------------------------------------
+        // ---- online softmax: raw-score running max, scale folded into the exp2 argument -----------------
         const int kbase = kt * A_KT;
-        const bool tail = kbase + A_KT > Lk;
-        float mx = -INFINITY;
+        if (kbase + A_KT > Lk) {           // tail tile only (wave-uniform): mask keys >= Lk
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float t = s[kb][i] * scale_log2e;
-                if (tail) {
+                for (int i = 0; i < 16; ++i) {
                     const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    t = key < Lk ? t : -INFINITY;
+                    s[kb][i] = key < Lk ? s[kb][i] : -INFINITY;
                 }
-                s[kb][i] = t;
-                mx = fmaxf(mx, t);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
+        {   // both halves of the wave hold the same 32 queries (different keys): exchange maxima
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(m_new > m_run)) {        // rescale only when some query's running max moved
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 3; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * scale_log2e;
         float psum = 0.f;
         bf16x8 pf[4];
 #pragma unroll
@@ -142,19 +151,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                 uint32_t pk[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float p0 = __builtin_amdgcn_exp2f(s[kb][8 * sh + 2 * jj] - m_new);
-                    const float p1 = __builtin_amdgcn_exp2f(s[kb][8 * sh + 2 * jj + 1] - m_new);
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * sh + 2 * jj], scale_log2e, -mc));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * sh + 2 * jj + 1], scale_log2e, -mc));
                     psum += p0 + p1;
                     pk[jj] = pack_bf16x2(p0, p1);
                 }
                 uint4 u = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 pf[2 * kb + sh] = *reinterpret_cast<bf16x8*>(&u);
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < 3; ++db)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        l_run += psum;
         // ---- O^T += V^T . P^T -------------------------------------------------------------------
 #pragma unroll
         for (int s16 = 0; s16 < 4; ++s16) {

@@ -4,6 +4,8 @@
 //     bias / erf-GELU / drop-path scale / fp32 residual epilogue staged through LDS so global stores
 //     are whole rows.
 //   * fp32 path: exact-fp32 LDS-tiled VALU GEMM (parity path, not performance critical).
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -14,6 +16,7 @@
 #define LBK 96
 #define L_ROWB 192                    // bytes per LDS row (96 bf16)
 #define L_STAGE_LD 100                // fp32 epilogue staging leading dim (floats)
+#define L_SMEM_BYTES (LBM * L_STAGE_LD * 4)  // 51200 >= slabs of the 128-row tile (43008)
 
 // LDS image of a [rows][96] bf16 slab: 12 16-byte chunks per row, chunk c of row r stored at
 // position (c + ((r>>2)&3)) % 12: ds_read_b128 by the 32x32x16 A/B fragment pattern (16-lane groups
@@ -43,14 +46,206 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <typename TA, typename TO>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(
+// fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one v_rcp;
+// libm erff costs 30-60 VALU instructions per element and made the fc1 epilogue VALU-bound.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erfv);
+}
+
+// Staging map: 16 lanes per row (12 carry a 16-byte chunk, 4 idle), rows tid/16 + 16*i.  The rotation
+// ((row>>2)&3) is then the same for every i, so LDS offsets are base + i*16*192 (immediates) and global
+// offsets are base + i*16*lda: no per-slab index arithmetic.
+template <typename TA, typename TO, int WM>   // WM = 32-row m-blocks per wave: tile = (128*WM) x 96
+__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(
     const TA* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
     TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
+    constexpr int BM = LBM * WM;
+    constexpr int NA = BM / 16;                // A row groups per thread per slab (8 or 16)
+    constexpr int NB = LBN / 16;               // 6
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + LBM * L_ROWB;
+    char* sB = smem + BM * L_ROWB;
+    float* stage = reinterpret_cast<float*>(smem);
+
+    const int ntn = N / LBN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % ntn;
+    const int64_t tm = tile / ntn;
+    const int64_t m0 = tm * BM;
+    const int n0 = tn * LBN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int srow = tid >> 4, schk = tid & 15;
+    const bool s_on = schk < 12;
+    const int s_lds = slab_off(srow, s_on ? schk : 0);   // + i*16*L_ROWB
+    const bool full_m = m0 + BM <= M;
+    const TA* a_ptr = a + (m0 + srow) * lda + 8 * (s_on ? schk : 0);
+    const bf16_t* w_ptr = w + (int64_t)(n0 + srow) * K + 8 * (s_on ? schk : 0);
+
+    f32x16 acc[WM][3];
+#pragma unroll
+    for (int mb = 0; mb < WM; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    // per-lane fragment offsets (same for A rows 32*j+r and B rows 32*nb+r: (row>>2)&3 == (r>>2)&3)
+    int foff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        int p = 2 * ks + h + ((r >> 2) & 3);
+        p = p >= 12 ? p - 12 : p;
+        foff[ks] = p * 16;
+    }
+    const char* fa = sA + (32 * WM * wave + r) * L_ROWB;
+    const char* fb = sB + r * L_ROWB;
+
+    uint4 ra[NA], rb[NB];
+    auto gload = [&](int k0) {
+        if (s_on) {
+            if (full_m) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = load_chunk8(a_ptr + (int64_t)i * 16 * lda + k0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    int64_t m = m0 + srow + 16 * i;
+                    m = m < M ? m : M - 1;  // clamp: rows >= M are never stored
+                    ra[i] = load_chunk8(a + m * lda + 8 * schk + k0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = load_chunk8(w_ptr + (int64_t)i * 16 * K + k0);
+        }
+    };
+
+    const int nk = K / LBK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous slab's fragment reads are done
+        if (s_on) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(sA + s_lds + i * 16 * L_ROWB) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(sB + s_lds + i * 16 * L_ROWB) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * LBK);  // prefetch next slab under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            bf16x8 af[WM];
+#pragma unroll
+            for (int mb = 0; mb < WM; ++mb) af[mb] = *reinterpret_cast<const bf16x8*>(fa + mb * 32 * L_ROWB + foff[ks]);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(fb + nb * 32 * L_ROWB + foff[ks]);
+#pragma unroll
+                for (int mb = 0; mb < WM; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr, acc[mb][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue, one 128-row pass per m-block: bias/GELU in accumulator layout -> fp32 LDS stage ->
+    //      whole-row coalesced pass (drop-path scale, residual, 16-byte stores) ------------------------------
+    constexpr int CWO = 16 / sizeof(TO);       // output elements per 16-byte store
+    constexpr int CPR = LBN / CWO;             // chunks per row (12 bf16 / 24 fp32)
+    constexpr int LPR = (CPR == 12) ? 16 : 32; // lanes per row (CPR of them active)
+    constexpr int RPI = 256 / LPR;             // rows per iteration
+    const int erow = tid / LPR, ec = tid % LPR;
+    const bool e_on = ec < CPR;
+#pragma unroll
+    for (int mb = 0; mb < WM; ++mb) {
+        __syncthreads();  // slabs (or the previous pass's stage) are dead
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int n = nb * 32 + r;
+            const float bv = (epilogue & MVIT_EPI_BIAS) ? bias[n0 + n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ml = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[mb][nb][i] + bv;
+                if (epilogue & MVIT_EPI_GELU) v = gelu_fast(v);
+                stage[ml * L_STAGE_LD + n] = v;
+            }
+        }
+        __syncthreads();
+        if (e_on) {
+#pragma unroll
+            for (int i = 0; i < 128 / RPI; ++i) {
+                const int row = erow + RPI * i;
+                // stage row (32*wave' + l) holds tile row 32*WM*wave' + 32*mb + l
+                const int64_t m = m0 + (row >> 5) * (32 * WM) + 32 * mb + (row & 31);
+                if (full_m || m < M) {
+                    float v[CWO];
+#pragma unroll
+                    for (int e = 0; e < CWO; e += 4) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(stage + row * L_STAGE_LD + CWO * ec + e);
+                        v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                    }
+                    if (row_scale) {
+                        const float sc = row_scale[m / rows_per_scale];
+#pragma unroll
+                        for (int e = 0; e < CWO; ++e) v[e] *= sc;
+                    }
+                    if (epilogue & MVIT_EPI_RESIDUAL) {
+#pragma unroll
+                        for (int e = 0; e < CWO; e += 4) {
+                            const float4 rr = load4(residual + m * ldr + n0 + CWO * ec + e);
+                            v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
+                        }
+                    }
+                    TO* dst = y + m * ldy + n0 + CWO * ec;
+                    if constexpr (sizeof(TO) == 2) {
+                        uint4 o;
+                        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                        *reinterpret_cast<uint4*>(dst) = o;
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16 A): slabs are 48 k wide (96-byte rows), double-buffered, filled by
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write), one barrier per slab.  The DMA writes LDS
+// linearly in lane order, so the bank-conflict swizzle is applied on the per-lane SOURCE address:
+// LDS chunk position P = row*6 + p holds logical chunk c = (p - ((row>>4)&1)) mod 6 of that row, and the
+// fragment reader applies the same rotation (ds_read_b128 by the 32x32x16 pattern is then conflict-free).
+// ------------------------------------------------------------------------------------------------
+#define DK 48
+#define D_ROWB 96
+#define D_A_BYTES (LBM * D_ROWB)   // 12288
+#define D_B_BYTES (LBN * D_ROWB)   // 9216
+#define D_BUF (D_A_BYTES + D_B_BYTES)
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <typename TO>
+__global__ __launch_bounds__(256, 2) void linear_dma_kernel(
+    const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
+    TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* stage = reinterpret_cast<float*>(smem);
 
     const int ntn = N / LBN;
@@ -59,127 +254,368 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
     const int64_t tm = tile / ntn;
     const int64_t m0 = tm * LBM;
     const int n0 = tn * LBN;
-
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
+    const bool full_m = m0 + LBM <= M;
 
-    // staging assignment: chunk q = tid + 256*i -> row q/12, chunk q%12
-    int a_row[6], a_chk[6];
+    // DMA source offsets (elements, relative to the tile's first row), fixed for the whole K loop
+    int a_off[3], b_off[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int q = tid + 256 * i;
-        a_row[i] = q / 12;
-        a_chk[i] = q - a_row[i] * 12;
+    for (int i = 0; i < 3; ++i) {
+        const int P = 64 * (3 * wave + i) + lane;          // A: 768 chunks, 12 wave-instructions
+        int row = P / 6;
+        const int ph = P - row * 6;
+        int c = ph - ((row >> 4) & 1);
+        c = c < 0 ? c + 6 : c;
+        if (!full_m && m0 + row >= M) row = (int)(M - 1 - m0);
+        a_off[i] = row * (int)lda + 8 * c;
+        const int Pb = 64 * (4 * i + wave) + lane;         // B: 576 chunks, 9 wave-instructions (wave 0 issues 3)
+        int rowb = Pb / 6;
+        const int phb = Pb - rowb * 6;
+        int cb = phb - ((rowb >> 4) & 1);
+        cb = cb < 0 ? cb + 6 : cb;
+        rowb = rowb < LBN ? rowb : LBN - 1;
+        b_off[i] = rowb * K + 8 * cb;
     }
-    int b_row[5], b_chk[5];
+    const bf16_t* a_tile = a + m0 * lda;
+    const bf16_t* w_tile = w + (int64_t)n0 * K;
+    const int nb_instr = (wave == 0) ? 3 : 2;
+
+    auto dma = [&](int k0, int buf) {
+        char* base = smem + buf * D_BUF;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int q = tid + 256 * i;
-        b_row[i] = q / 12;
-        b_chk[i] = q - b_row[i] * 12;
-    }
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(a_tile + a_off[i] + k0), (lptr_t*)(base + 1024 * (3 * wave + i)), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < nb_instr)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(w_tile + b_off[i] + k0),
+                                                 (lptr_t*)(base + D_A_BYTES + 1024 * (4 * i + wave)), 16, 0, 0);
+    };
 
     f32x16 acc[3];
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-
-    // per-lane fragment offsets (same for A rows 32*wave+r and B rows 32*nb+r: (row>>2)&3 == (r>>2)&3)
-    int foff[6];
+    int foff[3];
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        int p = 2 * ks + h + ((r >> 2) & 3);
-        p = p >= 12 ? p - 12 : p;
+    for (int ks = 0; ks < 3; ++ks) {
+        int p = 2 * ks + h + ((r >> 4) & 1);
+        p = p >= 6 ? p - 6 : p;
         foff[ks] = p * 16;
     }
-    const char* fa = sA + (32 * wave + r) * L_ROWB;
-    const char* fb = sB + r * L_ROWB;
+    const int fa_off = (32 * wave + r) * D_ROWB;
+    const int fb_off = D_A_BYTES + r * D_ROWB;
 
-    uint4 ra[6], rb[5];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            int64_t m = m0 + a_row[i];
-            m = m < M ? m : M - 1;  // clamp: rows >= M are never stored
-            ra[i] = load_chunk8(a + m * lda + k0 + 8 * a_chk[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            if (i < 4 || tid < 128) rb[i] = load_chunk8(w + (int64_t)(n0 + b_row[i]) * K + k0 + 8 * b_chk[i]);
-        }
-    };
-
-    const int nk = K / LBK;
-    gload(0);
+    const int nk = K / DK;
+    dma(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // previous slab's fragment reads are done
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of slab kt have landed
+        __syncthreads();                      // ... and everyone's; all reads of the other buffer are done
+        if (kt + 1 < nk) dma((kt + 1) * DK, (kt + 1) & 1);
+        const char* base = smem + (kt & 1) * D_BUF;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<uint4*>(sA + slab_off(a_row[i], a_chk[i])) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (i < 4 || tid < 128) *reinterpret_cast<uint4*>(sB + slab_off(b_row[i], b_chk[i])) = rb[i];
-        __syncthreads();
-        if (kt + 1 < nk) gload((kt + 1) * LBK);  // prefetch next slab under the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(fa + foff[ks]);
+        for (int ks = 0; ks < 3; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + fa_off + foff[ks]);
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(fb + nb * 32 * L_ROWB + foff[ks]);
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(base + fb_off + nb * 32 * D_ROWB + foff[ks]);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[nb], 0, 0, 0);
             }
         }
     }
-    __syncthreads();  // slabs dead -> reuse LDS as the fp32 staging tile
 
-    // ---- epilogue part 1: bias / GELU in accumulator layout, stage to LDS -----------------------
+    constexpr int CWO = 16 / sizeof(TO);
+    constexpr int CPR = LBN / CWO;
+    constexpr int LPR = (CPR == 12) ? 16 : 32;
+    constexpr int RPI = 256 / LPR;
+    const int erow = tid / LPR, ec = tid % LPR;
+    const bool e_on = ec < CPR;
+    __syncthreads();  // slabs dead
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
         const int n = nb * 32 + r;
         const float bv = (epilogue & MVIT_EPI_BIAS) ? bias[n0 + n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int m = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int ml = 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
             float v = acc[nb][i] + bv;
-            if (epilogue & MVIT_EPI_GELU) v = gelu_erf(v);
-            stage[m * L_STAGE_LD + n] = v;
+            if (epilogue & MVIT_EPI_GELU) v = gelu_fast(v);
+            stage[ml * L_STAGE_LD + n] = v;
         }
     }
     __syncthreads();
-    // ---- epilogue part 2: whole-row coalesced pass: scale, residual, store ------------------------
+    if (e_on) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int q = tid + 256 * i;        // 128 rows x 24 float4
-        const int row = q / 24, c4 = q - row * 24;
-        const int64_t m = m0 + row;
-        if (m < M) {
-            float4 v = *reinterpret_cast<const float4*>(stage + row * L_STAGE_LD + 4 * c4);
-            if (row_scale) {
-                const float s = row_scale[m / rows_per_scale];
-                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        for (int i = 0; i < 128 / RPI; ++i) {
+            const int row = erow + RPI * i;
+            const int64_t m = m0 + row;
+            if (full_m || m < M) {
+                float v[CWO];
+#pragma unroll
+                for (int e = 0; e < CWO; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(stage + row * L_STAGE_LD + CWO * ec + e);
+                    v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                }
+                if (row_scale) {
+                    const float sc = row_scale[m / rows_per_scale];
+#pragma unroll
+                    for (int e = 0; e < CWO; ++e) v[e] *= sc;
+                }
+                if (epilogue & MVIT_EPI_RESIDUAL) {
+#pragma unroll
+                    for (int e = 0; e < CWO; e += 4) {
+                        const float4 rr = load4(residual + m * ldr + n0 + CWO * ec + e);
+                        v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
+                    }
+                }
+                TO* dst = y + m * ldy + n0 + CWO * ec;
+                if constexpr (sizeof(TO) == 2) {
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(dst) = o;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
-            if (epilogue & MVIT_EPI_RESIDUAL) {
-                const float4 rr = load4(residual + m * ldr + n0 + 4 * c4);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            store4(y + m * ldy + n0 + 4 * c4, v);
         }
     }
 }
 
-#define L_SMEM_BYTES (LBM * L_STAGE_LD * 4)  // 51200 >= slabs (43008)
+template <typename TO>
+static int launch_linear_dma(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+                             int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                             int K, int epi, hipStream_t st) {
+    const int64_t nwg = ((M + LBM - 1) / LBM) * (N / LBN);
+    if (nwg > 0x7fffffff) return MVIT_EINVAL;
+    hipLaunchKernelGGL((linear_dma_kernel<TO>), dim3((unsigned)nwg), dim3(256), L_SMEM_BYTES, st, (const bf16_t*)a, lda,
+                       (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-tile LDS-DMA variant: 128 x 192 output tile, 4 waves (2 along M x 2 along N, 64x96 each),
+// 64-wide K slabs = one whole 128-byte line per row, double-buffered in LDS (80 KB -> 2 workgroups/CU) and
+// filled by global_load_lds_dwordx4 one slab ahead (raw s_barrier; the DMA stays in flight under the MFMAs).
+//
+// Measured reasons for this shape (rocprof PMC + ablation builds, M=50176 N=1152 K=384, MI355X):
+//   * 96-byte K segments straddle 128-B lines: ~1 GB of L2->L1 line traffic for 0.45 GB useful, 50 % of wave
+//     time in s_waitcnt  -> whole-line slabs, bigger tile.
+//   * an fp32 LDS-staged epilogue cost 40 % of the kernel at 1 workgroup/CU  -> the product is computed
+//     TRANSPOSED (A operand = weight rows, B operand = token rows), so each lane owns one output ROW and
+//     4 consecutive columns per accumulator quad; bias/GELU/residual are applied in registers and rows are
+//     stored straight from registers in 16-byte pieces (bf16: quads of the two half-waves are first paired
+//     with v_permlane32_swap).  No LDS round trip; 2 workgroups/CU overlap one's epilogue with the other's MFMAs.
+// LDS image: 128-byte rows, chunk c of row r at position c ^ ((r>>1)&7) (conflict-free ds_read_b128 for the
+// 32x32x16 fragment pattern); the DMA writes linearly, so the XOR is applied to the per-lane SOURCE address.
+// ------------------------------------------------------------------------------------------------
+#define G_BM 128
+#define G_BN 192
+#define G_BK 64
+#define G_ROWB 128
+#define G_PANEL_A (G_BM * G_ROWB)     // 16384
+#define G_PANEL_B (G_BN * G_ROWB)     // 24576
+#define G_BUF (G_PANEL_A + G_PANEL_B) // 40960
+#define G_SMEM (2 * G_BUF)            // 81920
+
+template <typename TO>
+__global__ __launch_bounds__(256, 2) void linear_big_kernel(
+    const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
+    TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int ntn = N / G_BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % ntn;
+    const int64_t tm = tile / ntn;
+    const int64_t m0 = tm * G_BM;
+    const int n0 = tn * G_BN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const bool full_m = m0 + G_BM <= M;
+
+    // DMA piece p (1 KiB = 8 rows x 128 B): lane -> row 8p + lane/8, position lane%8, logical chunk pos ^ swz(row)
+    // A panel: 16 pieces (4 per wave); B panel: 24 pieces (6 per wave)
+    int a_off[4], b_off[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (!full_m && m0 + row >= M) row = (int)(M - 1 - m0);
+        a_off[i] = row * (int)lda + 8 * c;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = 8 * (6 * wave + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        b_off[i] = row * K + 8 * c;
+    }
+    const bf16_t* a_tile = a + m0 * lda;
+    const bf16_t* w_tile = w + (int64_t)n0 * K;
+
+    auto dma = [&](int k0, int buf) {
+        char* base = smem + buf * G_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(a_tile + a_off[i] + k0), (lptr_t*)(base + 1024 * (4 * wave + i)), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(w_tile + b_off[i] + k0),
+                                             (lptr_t*)(base + G_PANEL_A + 1024 * (6 * wave + i)), 16, 0, 0);
+    };
+
+    // acc[mb][nb]: rows (registers) = n = 96*wn + 32*nb + (i&3) + 8*(i>>2) + 4*h ; column (lane) = m = 64*wm + 32*mb + r
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
+    const int fx_off = (64 * wm + r) * G_ROWB;                 // token rows  (MFMA B operand)
+    const int fw_off = G_PANEL_A + (96 * wn + r) * G_ROWB;     // weight rows (MFMA A operand)
+
+    const int nk = K / G_BK;
+    dma(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
+        __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other buffer
+        if (kt + 1 < nk && !(epilogue & 512)) dma((kt + 1) * G_BK, (kt + 1) & 1);
+        const char* base = smem + (kt & 1) * G_BUF;
+        if (epilogue & 1024) continue;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 xf[2], wf[3];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(base + fx_off + mb * 32 * G_ROWB + foff[ks]);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(base + fw_off + nb * 32 * G_ROWB + foff[ks]);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+
+    if (epilogue & 256) {   // DIAG build aid: skip the epilogue, keep the accumulators live
+        float t = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += acc[mb][nb][i];
+        if (t == 12345.678f) y[0] = (TO)0;
+        return;
+    }
+    // ---- epilogue from registers: lane = output row, quads of 4 consecutive columns ---------------------
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int64_t m = m0 + 64 * wm + 32 * mb + r;
+        const bool ok = full_m || m < M;
+        const float sc = (row_scale && ok) ? row_scale[m / rows_per_scale] : 1.f;
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int nbase = n0 + 96 * wn + 32 * nb + 4 * h;    // + 8*q
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+                if (epilogue & MVIT_EPI_BIAS) {
+                    const float4 bb = load4(bias + nbase + 8 * q);
+                    v[q].x += bb.x; v[q].y += bb.y; v[q].z += bb.z; v[q].w += bb.w;
+                }
+                if (epilogue & MVIT_EPI_GELU) {
+                    v[q].x = gelu_fast(v[q].x); v[q].y = gelu_fast(v[q].y);
+                    v[q].z = gelu_fast(v[q].z); v[q].w = gelu_fast(v[q].w);
+                }
+                if (row_scale) { v[q].x *= sc; v[q].y *= sc; v[q].z *= sc; v[q].w *= sc; }
+            }
+            if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (ok) {
+                        if (epilogue & MVIT_EPI_RESIDUAL) {
+                            const float4 rr = load4(residual + m * ldr + nbase + 8 * q);
+                            v[q].x += rr.x; v[q].y += rr.y; v[q].z += rr.z; v[q].w += rr.w;
+                        }
+                        *reinterpret_cast<float4*>(y + m * ldy + nbase + 8 * q) = v[q];
+                    }
+                }
+            } else {
+                // bf16 (no residual): lane (r,0) holds cols 8q..8q+3, lane (r,1) holds 8q+4..8q+7 of the same row.
+                // permlane32_swap(a = quad q, b = quad q+1): afterwards the lower half holds 8 consecutive columns of
+                // quad-pair q (16 B), the upper half those of quad-pair q+1.
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    uint32_t a0 = pack_bf16x2(v[q].x, v[q].y), a1 = pack_bf16x2(v[q].z, v[q].w);
+                    uint32_t b0 = pack_bf16x2(v[q + 1].x, v[q + 1].y), b1 = pack_bf16x2(v[q + 1].z, v[q + 1].w);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    // lower half: {own q lo4 | upper's q (cols +4)} ; upper half: {lower's q+1 | own q+1 (cols +4)}
+                    const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    if (ok) *reinterpret_cast<uint4*>(y + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (q + h)) = o;
+                }
+            }
+        }
+    }
+}
+
+template <typename TO>
+static int launch_linear_big(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+                             int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                             int K, int epi, hipStream_t st) {
+    const int64_t nwg = ((M + G_BM - 1) / G_BM) * (N / G_BN);
+    if (nwg > 0x7fffffff) return MVIT_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((linear_big_kernel<TO>), dim3((unsigned)nwg), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+                       (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
 
 template <typename TA, typename TO>
 static int launch_linear_mfma(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
                               int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
                               int K, int epi, hipStream_t st) {
-    const int64_t ntm = (M + LBM - 1) / LBM;
-    const int64_t nwg = ntm * (N / LBN);
-    if (nwg > 0x7fffffff) return MVIT_EINVAL;
-    hipLaunchKernelGGL((linear_mfma_kernel<TA, TO>), dim3((unsigned)nwg), dim3(256), L_SMEM_BYTES, st, (const TA*)a, lda,
-                       (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    // 256-row tiles (64x96 per wave) when that still leaves >= 2 workgroups per CU; else 128-row tiles
+    const int64_t nwg2 = ((M + 2 * LBM - 1) / (2 * LBM)) * (N / LBN);
+    // measured on MI355X: the 256-row tile (2 waves/SIMD) loses to the 128-row tile (3 waves/SIMD) on every shape
+    // of the model with this barrier-synchronous structure; kept for the pipelined version.
+    if (false && nwg2 >= 512 && sizeof(TA) == 2) {
+        if (nwg2 > 0x7fffffff) return MVIT_EINVAL;
+        constexpr int smem2 = 2 * LBM * L_ROWB + LBN * L_ROWB;   // 67584 >= stage (51200)
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<TA, TO, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess)
+                return MVIT_ELAUNCH;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((linear_mfma_kernel<TA, TO, 2>), dim3((unsigned)nwg2), dim3(256), smem2, st, (const TA*)a, lda,
+                           (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    } else {
+        const int64_t nwg = ((M + LBM - 1) / LBM) * (N / LBN);
+        hipLaunchKernelGGL((linear_mfma_kernel<TA, TO, 1>), dim3((unsigned)nwg), dim3(256), L_SMEM_BYTES, st, (const TA*)a,
+                           lda, (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    }
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -271,6 +707,21 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         return MVIT_EUNSUPPORTED;
 #define DISPATCH(TA, TO) \
     return launch_linear_mfma<TA, TO>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
+    static const bool use_dma = getenv("MVIT_GEMM_NO_DMA") == nullptr;
+    static const bool use_big = getenv("MVIT_GEMM_NO_BIG") == nullptr;
+    if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && K % G_BK == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
+        !(out_dtype == MVIT_BF16 && (epilogue & MVIT_EPI_RESIDUAL))) {
+        if (out_dtype == MVIT_BF16)
+            return launch_linear_big<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+        if (out_dtype == MVIT_F32)
+            return launch_linear_big<float>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+    }
+    if (a_dtype == MVIT_BF16 && use_dma && 128 * lda < (1ll << 31)) {
+        if (out_dtype == MVIT_BF16)
+            return launch_linear_dma<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+        if (out_dtype == MVIT_F32)
+            return launch_linear_dma<float>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+    }
     if (a_dtype == MVIT_BF16 && out_dtype == MVIT_BF16) DISPATCH(bf16_t, bf16_t);
     if (a_dtype == MVIT_BF16 && out_dtype == MVIT_F32) DISPATCH(bf16_t, float);
     if (a_dtype == MVIT_F32 && out_dtype == MVIT_F32) DISPATCH(float, float);

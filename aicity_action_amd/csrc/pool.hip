@@ -122,6 +122,232 @@ __global__ __launch_bounds__(256) void pool_conv_ln_kernel(const TA* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Tiled variant for spatial stride 1 and 2 (98 % of the pooled tokens).
+//
+// One workgroup owns an 8-wide x ROWS-high output tile of one (batch, head) and marches over the T
+// input frames: the current input frame's halo tile lives in LDS (double-buffered, next frame
+// prefetched through registers), every thread owns one channel PAIR (its 27x2 weights stay in
+// registers) and one output row of 8 tokens, and keeps three rolling accumulator sets (output frames
+// f-1, f, f+1) so each LDS value is read once per (dy) and used for 3 dt x 3 dx taps.  A finished frame
+// is staged in LDS as fp32, LayerNorm'ed by 4 lanes per token and stored as whole token rows.
+// HBM-bound target; VALU (fp32 FMA) is the co-limit: 2592 FMA per output token.
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__device__ __forceinline__ void load2(const TA* p, float& a, float& b);
+template <>
+__device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float& a, float& b) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    a = __uint_as_float(u << 16);
+    b = __uint_as_float(u & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) {
+    const float2 u = *reinterpret_cast<const float2*>(p);
+    a = u.x;
+    b = u.y;
+}
+
+template <typename TA, int S>
+struct PoolTile {
+    static constexpr int ROWS = (S == 1) ? 8 : 4;
+    static constexpr int XO = 8;
+    static constexpr int IH = S * (ROWS - 1) + 3;
+    static constexpr int IW = S * (XO - 1) + 3;
+    static constexpr int NT = 48 * ROWS;
+    static constexpr int NTOK = ROWS * XO;
+    static constexpr int CW = 16 / sizeof(TA);
+    static constexpr int CPT = 96 / CW;                 // 16-byte chunks per token
+    static constexpr int NCHUNK = IH * IW * CPT;
+    static constexpr int PF = (NCHUNK + NT - 1) / NT;   // prefetch registers (uint4) per thread
+    static constexpr int IN_BYTES = IH * IW * 96 * (int)sizeof(TA);
+    static constexpr int W_BYTES = 27 * 96 * 4;          // weights [tap][channel] fp32
+    static constexpr bool DB = (S == 1);                // double-buffered input tile + register prefetch
+    static constexpr int NBUF = DB ? 2 : 1;
+    static constexpr int SMEM = NBUF * IN_BYTES + NTOK * 96 * 4 + W_BYTES;
+};
+
+template <typename TA, int S>
+__global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
+    const TA* __restrict__ qkv, int64_t ld, int chan_off, const float* __restrict__ w, const float* __restrict__ gamma,
+    const float* __restrict__ beta, TA* __restrict__ out, int heads, int T, int H, int W, int Ho, int Wo, float eps) {
+    using P = PoolTile<TA, S>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* stage = reinterpret_cast<float*>(smem + P::NBUF * P::IN_BYTES);
+
+    const int tid = threadIdx.x;
+    const int cp = tid % 48, row = tid / 48;
+    const int tiles_x = (Wo + P::XO - 1) / P::XO;
+    const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int64_t Nin = (int64_t)T * H * W;
+    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + g * 96;
+    const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
+
+    float* wl = reinterpret_cast<float*>(smem + P::NBUF * P::IN_BYTES + P::NTOK * 96 * 4);
+    for (int i = tid; i < 27 * 96; i += P::NT) {
+        const int tap = i / 96, c = i - tap * 96;
+        wl[i] = w[c * 27 + tap];
+    }
+    const float* wmine = wl + 2 * cp;
+    // LayerNorm lane mapping (threads < NTOK*4): token = tid>>2, j = tid&3, 24 channels in CW-wide chunks j+4i
+    const int lj = tid & 3, ltok = tid >> 2;
+    constexpr int CW = P::CW, NCH = 24 / CW;
+
+    uint4 pf[P::PF];
+    int poff[P::PF];   // element offset of this thread's chunk inside one frame, -1 = zero padding / unused
+#pragma unroll
+    for (int i = 0; i < P::PF; ++i) {
+        const int c = tid + P::NT * i;
+        poff[i] = -1;
+        if (c < P::NCHUNK) {
+            const int tok = c / P::CPT, ch = c - tok * P::CPT;
+            const int iy = tok / P::IW, ix = tok - iy * P::IW;
+            const int y = y_in0 + iy, x = x_in0 + ix;
+            if (y >= 0 && y < H && x >= 0 && x < W) poff[i] = (int)((y * W + x) * ld) + ch * CW;
+        }
+    }
+    const int frame_stride = (int)((int64_t)H * W * ld);
+    auto prefetch = [&](int f) {
+        const TA* fb = base + (int64_t)f * frame_stride;
+#pragma unroll
+        for (int i = 0; i < P::PF; ++i) {
+            pf[i] = make_uint4(0, 0, 0, 0);
+            if (poff[i] >= 0) pf[i] = *reinterpret_cast<const uint4*>(fb + poff[i]);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < P::PF; ++i) {
+            const int c = tid + P::NT * i;
+            if (c < P::NCHUNK) *reinterpret_cast<uint4*>(smem + buf * P::IN_BYTES + c * 16) = pf[i];
+        }
+    };
+
+    float acc[3][P::XO][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int x = 0; x < P::XO; ++x) acc[a][x][0] = acc[a][x][1] = 0.f;
+
+    auto finalize = [&](int fo) {   // acc[0] holds output frame fo; all threads call this (barriers inside)
+#pragma unroll
+        for (int x = 0; x < P::XO; ++x)
+            *reinterpret_cast<float2*>(stage + (row * P::XO + x) * 96 + 2 * cp) = make_float2(acc[0][x][0], acc[0][x][1]);
+        __syncthreads();
+        if (tid < P::NTOK * 4) {
+            float v[24];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < CW; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(stage + ltok * 96 + CW * (lj + 4 * i) + e);
+                    v[i * CW + e] = t4.x; v[i * CW + e + 1] = t4.y; v[i * CW + e + 2] = t4.z; v[i * CW + e + 3] = t4.w;
+                }
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 24; ++e) sum += v[e];
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float mean = sum * (1.0f / 96.0f);
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 24; ++e) {
+                v[e] -= mean;
+                sq += v[e] * v[e];
+            }
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            const float rstd = 1.0f / sqrtf(sq * (1.0f / 96.0f) + eps);
+            const int yo = ty0 + ltok / P::XO, xo = tx0 + ltok % P::XO;
+            if (yo < Ho && xo < Wo) {
+                TA* o = out + (((int64_t)bh * T + fo) * Ho * Wo + (int64_t)yo * Wo + xo) * 96;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c0 = CW * (lj + 4 * i);
+#pragma unroll
+                    for (int e = 0; e < CW; e += 4) {
+                        float4 r;
+                        r.x = v[i * CW + e] * rstd * gamma[c0 + e] + beta[c0 + e];
+                        r.y = v[i * CW + e + 1] * rstd * gamma[c0 + e + 1] + beta[c0 + e + 1];
+                        r.z = v[i * CW + e + 2] * rstd * gamma[c0 + e + 2] + beta[c0 + e + 2];
+                        r.w = v[i * CW + e + 3] * rstd * gamma[c0 + e + 3] + beta[c0 + e + 3];
+                        store4(o + c0 + e, r);
+                    }
+                }
+            }
+        }
+    };
+
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    for (int f = 0; f < T; ++f) {
+        if (P::DB && f + 1 < T) prefetch(f + 1);
+        const int cur = P::DB ? (f & 1) : 0;
+        const TA* tile = reinterpret_cast<const TA*>(smem + cur * P::IN_BYTES) + 2 * cp;
+        const float* wm = wmine;
+        asm volatile("" : "+v"(wm));   // keep the 54 weight reads inside the loop (LICM would pin 54 VGPRs)
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+            float xin[P::IW][2];
+            const TA* rp = tile + (S * row + dy) * P::IW * 96;
+#pragma unroll
+            for (int ix = 0; ix < P::IW; ++ix) load2<TA>(rp + ix * 96, xin[ix][0], xin[ix][1]);
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                // input frame f is tap dt of output frame f + 1 - dt  -> accumulator set 2 - dt
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float2 wv = *reinterpret_cast<const float2*>(wm + ((dt * 3 + dy) * 3 + dx) * 96);
+                    const float w0 = wv.x, w1 = wv.y;
+#pragma unroll
+                    for (int x = 0; x < P::XO; ++x) {
+                        acc[2 - dt][x][0] = fmaf(w0, xin[S * x + dx][0], acc[2 - dt][x][0]);
+                        acc[2 - dt][x][1] = fmaf(w1, xin[S * x + dx][1], acc[2 - dt][x][1]);
+                    }
+                }
+            }
+        }
+        // acc[0] = output frame f-1 is complete
+        if (f >= 1) finalize(f - 1);
+        else __syncthreads();
+        if (f + 1 < T) {
+            if (!P::DB) prefetch(f + 1);   // single buffer: every thread is past its tile reads (barrier above)
+            commit(P::DB ? ((f + 1) & 1) : 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < P::XO; ++x) {
+            acc[0][x][0] = acc[1][x][0]; acc[0][x][1] = acc[1][x][1];
+            acc[1][x][0] = acc[2][x][0]; acc[1][x][1] = acc[2][x][1];
+            acc[2][x][0] = 0.f; acc[2][x][1] = 0.f;
+        }
+    }
+    finalize(T - 1);
+}
+
+template <typename TA, int S>
+static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                             const float* beta, void* out, int B, int heads, int T, int H, int W, int Ho, int Wo,
+                             float eps, hipStream_t st) {
+    using P = PoolTile<TA, S>;
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pool_tiled_kernel<TA, S>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
+                       beta, (TA*)out, heads, T, H, W, Ho, Wo, eps);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
                                      const float* beta, void* out, int B, int heads, int T, int H, int W, int stride_hw,
                                      float eps, int act_dtype, void* stream) {
@@ -133,6 +359,16 @@ extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, 
     int64_t blocks = (total + 63) / 64;
     if (blocks > 16384) blocks = 16384;
     hipStream_t st = as_stream(stream);
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
+    if (stride_hw == 1 || stride_hw == 2) {
+        if (act_dtype == MVIT_BF16) {
+            if (stride_hw == 1) return launch_pool_tiled<bf16_t, 1>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+            return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+        }
+        if (stride_hw == 1) return launch_pool_tiled<float, 1>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+        return launch_pool_tiled<float, 2>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+    }
     if (act_dtype == MVIT_F32)
         hipLaunchKernelGGL((pool_conv_ln_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)qkv, ld,
                            chan_off, w, gamma, beta, (float*)out, B, heads, T, H, W, Ho, Wo, stride_hw, eps);

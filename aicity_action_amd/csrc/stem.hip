@@ -80,12 +80,175 @@ __global__ __launch_bounds__(256) void stem_f32_kernel(const float* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA path: persistent implicit GEMM.
+//   K ordering k = (ci*3+dt)*7+dy) * 8 + dx  (63 tap rows + 1 zero row, dx padded 7 -> 8): K = 512 = 32
+//   k-steps of 16; the A fragment of a token is then 8 CONSECUTIVE input pixels of one (ci,dt,dy) row --
+//   two ds_read_b64 from a bf16 halo patch in LDS, no im2col buffer.
+//   One workgroup per CU walks 1x8x16-token tiles.  Waves 0-2 each own one 32-channel block with its
+//   whole 32x512 weight slab resident in 128 VGPRs (B fragments) and compute 128 tokens x 32 channels;
+//   wave 3 is the loader: it converts the next tile's fp32 halo patch to bf16 into the other LDS buffer
+//   while the MFMA waves run.  Output rows are written 128 B (32 fp32 channels) per half-wave with
+//   bias + separable position embedding fused.
+// ------------------------------------------------------------------------------------------------
+#define SM_TY 8
+#define SM_TX 16
+#define SM_PH 35                       // 4*8+3 patch rows
+#define SM_ROWB 144                    // 72 bf16 per patch row (68 used)
+#define SM_PLANE (SM_PH * SM_ROWB)     // 5040
+#define SM_PATCH (9 * SM_PLANE)        // 45360
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restrict__ clip, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ pos_s,
+                                                           const float* __restrict__ pos_t, float* __restrict__ x, int B,
+                                                           int T, int S, int To, int So, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) char patch[2][SM_PATCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_per_frame = tiles_x * tiles_y;
+    const int ntiles = B * To * tiles_per_frame;
+
+    // ---- B fragments (compute waves): W[n = 32*wave + r][row63 = 2s+h][dx = j] ---------------------
+    bf16x8 bfrag[32];
+    if (wave < 3) {
+        const float* wn = w + (int64_t)(32 * wave + r) * 441;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int row = 2 * s + h;
+            uint32_t pk[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float a = (row < 63) ? wn[row * 7 + 2 * jj] : 0.f;
+                const float b2 = (row < 63 && 2 * jj + 1 < 7) ? wn[row * 7 + 2 * jj + 1] : 0.f;
+                pk[jj] = pack_bf16x2(a, b2);
+            }
+            uint4 u = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            bfrag[s] = *reinterpret_cast<bf16x8*>(&u);
+        }
+    }
+
+    auto fill = [&](int tile, char* dst) {   // loader wave only
+        const int b = tile / (To * tiles_per_frame);
+        int rem = tile - b * (To * tiles_per_frame);
+        const int to = rem / tiles_per_frame;
+        rem -= to * tiles_per_frame;
+        const int ty0 = (rem / tiles_x) * SM_TY, tx0 = (rem % tiles_x) * SM_TX;
+        const int rig = lane / 17, seg = lane - rig * 17;
+        const bool lane_on = lane < 51;
+        const int xs = 4 * tx0 - 3 + 4 * seg;
+        for (int rg0 = 0; rg0 < 105; rg0 += 35) {   // 3 batches of 35 16-byte loads in flight per lane
+            f4u v[35];
+#pragma unroll
+            for (int u = 0; u < 35; ++u) {
+                v[u] = (f4u){0.f, 0.f, 0.f, 0.f};
+                const int row = 3 * (rg0 + u) + rig;
+                if (lane_on && rg0 + u < 105) {
+                    const int p = row / SM_PH, py = row - p * SM_PH;
+                    const int ci = p / 3, dt = p - ci * 3;
+                    const int ti = 2 * to + dt - 1, yi = 4 * ty0 - 3 + py;
+                    if (ti >= 0 && ti < T && yi >= 0 && yi < S) {
+                        const float* src = clip + ((((int64_t)b * 3 + ci) * T + ti) * S + yi) * S;
+                        if (xs >= 0 && xs + 3 < S) {
+                            v[u] = *reinterpret_cast<const f4u*>(src + xs);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (xs + e >= 0 && xs + e < S) v[u][e] = src[xs + e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 35; ++u) {
+                const int row = 3 * (rg0 + u) + rig;
+                if (lane_on && rg0 + u < 105) {
+                    uint2 o;
+                    o.x = pack_bf16x2(v[u][0], v[u][1]);
+                    o.y = pack_bf16x2(v[u][2], v[u][3]);
+                    *reinterpret_cast<uint2*>(dst + row * SM_ROWB + 8 * seg) = o;
+                }
+            }
+        }
+    };
+
+    // A-fragment lane base: token r of m-block mb -> (yo_l = 2*mb + (r>>4), xo_l = r&15)
+    const int a_base = (4 * (r >> 4)) * SM_ROWB + 8 * (r & 15);
+    const int hx = h * (SM_PLANE - 7 * SM_ROWB);   // extra offset when row 2s+1 starts the next (ci,dt) plane
+    const float bias_v = (wave < 3) ? bias[32 * wave + r] : 0.f;
+
+    int tile = blockIdx.x;
+    if (wave == 3 && tile < ntiles) fill(tile, patch[0]);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        if (wave == 3) {
+            if (tile + (int)gridDim.x < ntiles) fill(tile + gridDim.x, patch[buf ^ 1]);
+        } else {
+            const char* pb = patch[buf] + a_base;
+            f32x16 acc[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const int row0 = 2 * s;                       // tap row of lane-half 0
+                const int c0 = (row0 / 7) * SM_PLANE + (row0 % 7) * SM_ROWB;
+                int off = c0;
+                if (s < 31) {
+                    off += h * SM_ROWB;
+                    if (row0 % 7 == 6) off += hx;
+                }                                             // s == 31: row 63 has zero weights, read row 62 again
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const char* ap = pb + off + mb * (8 * SM_ROWB);
+                    const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
+                    uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), bfrag[s], acc[mb], 0, 0, 0);
+                }
+            }
+            // epilogue: + bias + pos_spatial[hw] + pos_temporal[t], token-major fp32
+            const int b = tile / (To * tiles_per_frame);
+            int rem = tile - b * (To * tiles_per_frame);
+            const int to = rem / tiles_per_frame;
+            rem -= to * tiles_per_frame;
+            const int ty0 = (rem / tiles_x) * SM_TY, tx0 = (rem % tiles_x) * SM_TX;
+            const int c = 32 * wave + r;
+            const float add_t = bias_v, pt = pos_t[to * 96 + c];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int tl = (i & 3) + 8 * (i >> 2) + 4 * h;      // token within the m-block
+                    const int yo = ty0 + 2 * mb + (tl >> 4), xo = tx0 + (tl & 15);
+                    if (yo < So && xo < So) {
+                        const int hw = yo * So + xo;
+                        x[(((int64_t)b * To + to) * So * So + hw) * 96 + c] = (acc[mb][i] + add_t) + (pos_s[(int64_t)hw * 96 + c] + pt);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int mvit_stem_fwd(const float* clip, const float* w, const float* bias, const float* pos_spatial,
                              const float* pos_temporal, float* x, int B, int T, int S, int act_dtype, void* stream) {
     if (!clip || !w || !bias || !pos_spatial || !pos_temporal || !x || B <= 0 || T <= 0 || S <= 0) return MVIT_EINVAL;
     if ((T & 1) || (S & 3)) return MVIT_EUNSUPPORTED;
-    (void)act_dtype;
     const int To = T / 2, So = S / 4;
+    if (act_dtype == MVIT_BF16) {
+        const int tiles_x = (So + SM_TX - 1) / SM_TX, tiles_y = (So + SM_TY - 1) / SM_TY;
+        const int ntiles = B * To * tiles_x * tiles_y;
+        const int grid = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(grid), dim3(256), 0, as_stream(stream), clip, w, bias, pos_spatial,
+                           pos_temporal, x, B, T, S, To, So, tiles_x, tiles_y);
+        MVIT_LAUNCH_CHECK();
+        return MVIT_OK;
+    }
     const int tiles = ((So + ST_TX - 1) / ST_TX) * ((So + ST_TY - 1) / ST_TY);
     dim3 grid(tiles, To, B);
     hipLaunchKernelGGL(stem_f32_kernel, grid, dim3(256), 0, as_stream(stream), clip, w, bias, pos_spatial, pos_temporal,

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of single C-ABI operators on cuda:0 (timing with events on the launch stream).
+
+    python tools/opbench.py gemm M N K [epi] [reps]     # bf16 a/w/out
+    python tools/opbench.py attn B heads Lq Lk [reps]
+    python tools/opbench.py pool B heads T H W stride [reps]
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from aicity_action_amd import _hip  # noqa: E402
+
+L = _hip.lib()
+dev = "cuda:0"
+st = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    op = sys.argv[1]
+    a = sys.argv[2:]
+    if op == "gemm":
+        M, N, K = int(a[0]), int(a[1]), int(a[2])
+        epi = a[3] if len(a) > 3 else "b"
+        reps = int(a[4]) if len(a) > 4 else 20
+        x = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        bias = torch.randn(N, device=dev)
+        res = torch.randn(M, N, device=dev) if "r" in epi else None
+        out_f32 = "r" in epi
+        y = torch.empty(M, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        flags = _hip.EPI_BIAS | (_hip.EPI_GELU if "g" in epi else 0) | (_hip.EPI_RESIDUAL if "r" in epi else 0) | int(os.environ.get("DIAG", "0"))
+
+        def fn():
+            _hip.check(L.mvit_linear_fwd(_hip.ptr(x), _hip.BF16, K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(res), N, None, 0,
+                                         _hip.ptr(y), _hip.F32 if out_f32 else _hip.BF16, N, M, N, K, flags, _hip.BF16, st))
+        ms = timeit(fn, reps)
+        fl = 2.0 * M * N * K
+        by = M * K * 2 + N * K * 2 + M * N * (4 if out_f32 else 2) + (M * N * 4 if res is not None else 0)
+        print("gemm M=%d N=%d K=%d epi=%s: %.1f us  %.1f TFLOP/s  %.2f TB/s" % (M, N, K, epi, ms * 1e3, fl / ms / 1e9, by / ms / 1e9))
+    elif op == "attn":
+        B, h, Lq, Lk = (int(v) for v in a[:4])
+        reps = int(a[4]) if len(a) > 4 else 20
+        q = torch.randn(B, h, Lq, 96, device=dev).bfloat16()
+        k = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
+        v = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
+        o = torch.empty(B, Lq, h * 96, device=dev, dtype=torch.bfloat16)
+
+        def fn():
+            _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), B, h, Lq, Lk, 96 ** -0.5, 1,
+                                            _hip.BF16, st))
+        ms = timeit(fn, reps)
+        print("attn B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s" % (B, h, Lq, Lk, ms * 1e3, 4.0 * B * h * Lq * Lk * 96 / ms / 1e9))
+    elif op == "pool":
+        B, h, T, H, W, s = (int(v) for v in a[:6])
+        reps = int(a[6]) if len(a) > 6 else 20
+        C = 96 * h
+        qkv = torch.randn(B, T * H * W, 3 * C, device=dev).bfloat16()
+        w = torch.randn(96, 27, device=dev) * 0.2
+        g, bt = torch.ones(96, device=dev), torch.zeros(96, device=dev)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        out = torch.empty(B, h, T * Ho * Wo, 96, device=dev, dtype=torch.bfloat16)
+
+        def fn():
+            _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * C, 0, _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt), _hip.ptr(out),
+                                               B, h, T, H, W, s, 1e-5, _hip.BF16, st))
+        ms = timeit(fn, reps)
+        ntok = B * h * T * Ho * Wo
+        print("pool B=%d h=%d THW=%dx%dx%d s=%d: %.1f us  %.2f Gtok/s  %.2f TB/s(out+in slice)" % (
+            B, h, T, H, W, s, ms * 1e3, ntok / ms / 1e6, (ntok * 192 + B * h * T * H * W * 192) / ms / 1e9))
+
+
+if __name__ == "__main__":
+    main()
