@@ -28,12 +28,32 @@ _SIGS = {
     "mvit_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
     "mvit_linear_fwd": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_i, c_p]),
     "mvit_pool_conv_ln_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
-    "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "mvit_maxpool_skip_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_workspace_bytes": (c_l, [c_i, c_i, c_i]),
     "mvit_head_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "mvit_cast_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_p]),
+    "mvit_layernorm_bwd_workspace_bytes": (c_l, [c_i]),
+    "mvit_layernorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p]),
+    "mvit_gelu_fwd": (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    "mvit_gelu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
+    "mvit_linear_wgrad": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p]),
+    "mvit_colsum_workspace_bytes": (c_l, [c_i]),
+    "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),
+    "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "mvit_attention_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mvit_pool_bwd_workspace_bytes": (c_l, []),
+    "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "mvit_maxpool_skip_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mvit_head_ln_partial": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "mvit_head_project_train": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_head_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_soft_ce": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    "mvit_mt_chunk_bytes": (c_i, []),
+    "mvit_grad_norm": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p]),
+    "mvit_adamw_step": (c_i, [c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
 }
 EXPORTS = tuple(_SIGS)
 

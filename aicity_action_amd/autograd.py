@@ -1,11 +1,333 @@
-"""Training path (forward with saved activations + hand-written backward kernels).
+"""Training path: forward that keeps activations + hand-written HIP backward, glued with torch.autograd.
 
-Round-1 status: the backward kernels are not built yet, so asking for gradients fails loudly
-instead of silently falling back to eager PyTorch.
+One ``autograd.Function`` per stem / block / head, so the reference's own loop (``loss.backward()``,
+``clip_grad_norm_``, ``optimizer.step()``, DDP bucketed all-reduce overlapping with the per-block backward) works
+unchanged on the module's ordinary ``nn.Parameter``s (tools/train_net.py:201-246).  Every arithmetic step is a C-ABI
+kernel; torch supplies allocation, the RNG draws for drop-path / dropout (slowfast/models/common.py:46-59,
+head_helper.py:410-411) and the autograd graph.
+
+Mixed-precision policy of the bf16 path: MFMA operands and stored activations bf16; residual stream, LayerNorm
+statistics, softmax statistics, accumulators, parameter gradients and optimizer state fp32 (fp32 masters).
 """
+import torch
+
+from . import _hip
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev)
+
+
+class _Ctx(object):
+    """Per-model helper: dtype policy + cached (transposed) low-precision weights."""
+
+    def __init__(self, model):
+        self.m = model
+        self.L = _hip.lib()
+        self.act = _hip.BF16 if model.precision == "bf16" else _hip.F32
+        self.adt = torch.bfloat16 if self.act == _hip.BF16 else torch.float32
+
+    def w(self, p):
+        return self.m._w(p, self.act)
+
+    def wt(self, p):
+        """[K][N] transposed copy in the activation dtype (operand of the data-gradient GEMM)."""
+        cache = self.m._bf16_cache
+        key = ("t", id(p))
+        ent = cache.get(key)
+        if ent is None or ent[0] != p._version or ent[1].device != p.device:
+            t = p.detach().t().contiguous()
+            if self.act == _hip.BF16:
+                buf = torch.empty(t.shape, dtype=torch.bfloat16, device=p.device)
+                _hip.check(self.L.mvit_cast_f32_to_bf16(_hip.ptr(t), _hip.ptr(buf), t.numel(), _st()), "cast")
+                t = buf
+            ent = (p._version, t)
+            cache[key] = ent
+        return ent[1]
+
+    # y = a . w^T (+bias)(gelu)(*row_scale)(+residual)
+    def linear(self, a, w, bias, out_dtype, residual=None, gelu=False, row_scale=None, rps=0):
+        M, K = a.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=out_dtype, device=a.device)
+        epi = (_hip.EPI_BIAS if bias is not None else 0) | (_hip.EPI_GELU if gelu else 0) | (
+            _hip.EPI_RESIDUAL if residual is not None else 0)
+        adt = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
+        odt = _hip.BF16 if out_dtype == torch.bfloat16 else _hip.F32
+        _hip.check(self.L.mvit_linear_fwd(_hip.ptr(a), adt, K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(residual), N,
+                                          _hip.ptr(row_scale), rps, _hip.ptr(y), odt, N, M, N, K, epi, self.act, _st()),
+                   "linear %dx%dx%d" % (M, N, K))
+        return y
+
+    def wgrad(self, a, dy, N, K, row_scale=None, rps=0):
+        dW = torch.zeros(N, K, dtype=torch.float32, device=a.device)
+        adt = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
+        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
+                                            a.shape[0], N, K, self.act, _st()), "wgrad")
+        return dW
+
+    def colsum(self, dy, row_scale=None, rps=0):
+        M, N = dy.shape
+        out = torch.empty(N, dtype=torch.float32, device=dy.device)
+        ws = _ws(self.L.mvit_colsum_workspace_bytes(N), dy.device)
+        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        _hip.check(self.L.mvit_colsum(_hip.ptr(dy), ddt, M, N, _hip.ptr(row_scale), rps, _hip.ptr(out), 0, _hip.ptr(ws), _st()),
+                   "colsum")
+        return out
+
+    def ln_fwd(self, x, norm):
+        rows, C = x.shape
+        y = torch.empty(rows, C, dtype=self.adt, device=x.device)
+        _hip.check(self.L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(y), rows, C,
+                                             norm.eps, self.act, _st()), "ln")
+        return y
+
+    def ln_bwd(self, x, norm, dy, dx, accumulate, rows_per_dy=1, dy_scale=1.0):
+        rows, C = x.shape
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _ws(self.L.mvit_layernorm_bwd_workspace_bytes(C), x.device)
+        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        _hip.check(self.L.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
+                                             _hip.ptr(dx), 1 if accumulate else 0, _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws),
+                                             rows, C, norm.eps, _st()), "ln_bwd")
+        return dg, db
+
+
+def _block_params(blk, g):
+    at = blk.attn
+    ps = [blk.norm1.weight, blk.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
+          at.pool_q.weight, at.norm_q.weight, at.norm_q.bias, at.pool_k.weight, at.norm_k.weight, at.norm_k.bias,
+          at.pool_v.weight, at.norm_v.weight, at.norm_v.bias, blk.norm2.weight, blk.norm2.bias,
+          blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+    if g.expand:
+        ps += [blk.proj_max_pool.weight, blk.proj_max_pool.bias]
+    return ps
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, w, b, ps, pt, hx):
+        m = hx.m
+        B, _, T, S, _ = clip.shape
+        Tp, Hp, Wp = m.patch_dims
+        x = torch.empty(B, Tp * Hp * Wp, 96, dtype=torch.float32, device=clip.device)
+        _hip.check(hx.L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(w), _hip.ptr(b), _hip.ptr(ps), _hip.ptr(pt), _hip.ptr(x), B, T, S,
+                                      hx.act, _st()), "stem")
+        ctx.hx, ctx.clip = hx, clip
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        hx, clip = ctx.hx, ctx.clip
+        m = hx.m
+        dx = dx.contiguous()
+        B, _, T, S, _ = clip.shape
+        dev = clip.device
+        dW = torch.zeros(96, 3, 3, 7, 7, dtype=torch.float32, device=dev)
+        dps = torch.zeros_like(m.pos_embed_spatial)
+        dpt = torch.zeros_like(m.pos_embed_temporal)
+        _hip.check(hx.L.mvit_stem_bwd(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, _st()),
+                   "stem_bwd")
+        db = hx.colsum(dx.view(-1, 96))
+        return None, dW, db, dps, dpt, None
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hx, g, blk, dp1, dp2, *params):
+        L, act, adt = hx.L, hx.act, hx.adt
+        dev = x.device
+        at = blk.attn
+        B = x.shape[0]
+        T, H, W = g.thw_in
+        N, Lq, Lk = g.n_in, g.lq, g.lk
+        M, Mq = B * N, B * Lq
+        Cin, Cout, h = g.dim_in, g.dim_out, g.heads
+        x2 = x.view(M, Cin)
+        u = hx.ln_fwd(x2, blk.norm1)
+        qkv = hx.linear(u, hx.w(at.qkv.weight), at.qkv.bias, adt)
+        q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
+        k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
+        v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
+        for which, (buf, conv, norm, stride) in enumerate(((q, at.pool_q, at.norm_q, g.stride_q[1]),
+                                                           (k, at.pool_k, at.norm_k, g.stride_kv[1]),
+                                                           (v, at.pool_v, at.norm_v, g.stride_kv[1]))):
+            _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
+                                               _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W, stride, norm.eps, act, _st()),
+                       "pool")
+        o = torch.empty(Mq, Cout, dtype=adt, device=dev)
+        lse = torch.empty(B, h, Lq, dtype=torch.float32, device=dev)
+        addq = 1 if hx.m.use_query_residual_pool else 0
+        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5,
+                                        addq, act, _st()), "attention")
+        r = x2
+        r_full = None
+        if g.expand:
+            r = hx.linear(x2, hx.w(blk.proj_max_pool.weight), blk.proj_max_pool.bias, torch.float32)
+        if not g.skip_is_identity:
+            r_full = r
+            r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r_full), _hip.ptr(r), B, T, H, W, Cout, _st()), "maxpool")
+        y = hx.linear(o, hx.w(at.proj.weight), at.proj.bias, torch.float32, residual=r, row_scale=dp1, rps=Lq)
+        vn = hx.ln_fwd(y, blk.norm2)
+        pre = hx.linear(vn, hx.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, adt)
+        hid = torch.empty_like(pre)
+        _hip.check(L.mvit_gelu_fwd(_hip.ptr(pre), _hip.ptr(hid), pre.numel(), act, _st()), "gelu")
+        out = hx.linear(hid, hx.w(blk.mlp.fc2.weight), blk.mlp.fc2.bias, torch.float32, residual=y, row_scale=dp2, rps=Lq)
+        ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, addq
+        ctx.saved = (x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2)
+        return out.view(B, Lq, Cout)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        hx, g, blk = ctx.hx, ctx.g, ctx.blk
+        L, act, adt = hx.L, hx.act, hx.adt
+        x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2 = ctx.saved
+        ctx.saved = None
+        at = blk.attn
+        dev = x2.device
+        B = q.shape[0]
+        T, H, W = g.thw_in
+        N, Lq, Lk = g.n_in, g.lq, g.lk
+        M, Mq = B * N, B * Lq
+        Cin, Cout, h = g.dim_in, g.dim_out, g.heads
+        d_out = d_out.contiguous().view(Mq, Cout)
+        # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
+        dW2 = hx.wgrad(hid, d_out, Cout, 4 * Cout, dp2, Lq)
+        db2 = hx.colsum(d_out, dp2, Lq)
+        d_hid = hx.linear(d_out, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=dp2, rps=Lq)
+        d_pre = torch.empty_like(d_hid)
+        _hip.check(L.mvit_gelu_bwd(_hip.ptr(pre), _hip.ptr(d_hid), _hip.ptr(d_pre), pre.numel(), act, _st()), "gelu_bwd")
+        del d_hid
+        dW1 = hx.wgrad(vn, d_pre, 4 * Cout, Cout)
+        db1 = hx.colsum(d_pre)
+        d_vn = hx.linear(d_pre, hx.wt(blk.mlp.fc1.weight), None, adt)
+        del d_pre
+        d_y = d_out.clone()
+        dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, True)
+        del d_vn
+        # ---- attention branch: y = r + dp1 * proj(o) ------------------------------------------------------
+        dWp = hx.wgrad(o, d_y, Cout, Cout, dp1, Lq)
+        dbp = hx.colsum(d_y, dp1, Lq)
+        d_o = hx.linear(d_y, hx.wt(at.proj.weight), None, adt, row_scale=dp1, rps=Lq)
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        ws = _ws(L.mvit_attention_bwd_workspace_bytes(B, h, Lq), dev)
+        _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(d_o), _hip.ptr(dq),
+                                        _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
+                   "attention_bwd")
+        del d_o
+        d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)
+        pws = _ws(L.mvit_pool_bwd_workspace_bytes(), dev)
+        pool_grads = []
+        for which, (dbuf, conv, norm, stride) in enumerate(((dq, at.pool_q, at.norm_q, g.stride_q[1]),
+                                                            (dk, at.pool_k, at.norm_k, g.stride_kv[1]),
+                                                            (dv, at.pool_v, at.norm_v, g.stride_kv[1]))):
+            dconv = torch.empty_like(dbuf)
+            dw = torch.zeros(96, 1, 3, 3, 3, dtype=torch.float32, device=dev)
+            dgm = torch.empty(96, dtype=torch.float32, device=dev)
+            dbt = torch.empty(96, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_pool_conv_ln_bwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
+                                               _hip.ptr(dbuf), _hip.ptr(dconv), _hip.ptr(d_qkv), _hip.ptr(dw), _hip.ptr(dgm),
+                                               _hip.ptr(dbt), 0, _hip.ptr(pws), B, h, T, H, W, stride, norm.eps, act, _st()),
+                       "pool_bwd")
+            pool_grads += [dw, dgm, dbt]
+        dWqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
+        dbqkv = hx.colsum(d_qkv)
+        d_u = hx.linear(d_qkv, hx.wt(at.qkv.weight), None, adt)
+        del d_qkv
+        # ---- skip path ------------------------------------------------------------------------------------
+        d_r = d_y
+        if r_full is not None:
+            d_rf = torch.empty(M, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_maxpool_skip_bwd(_hip.ptr(r_full), _hip.ptr(d_r), _hip.ptr(d_rf), B, T, H, W, Cout, _st()), "maxpool_bwd")
+            d_r = d_rf
+        extra = []
+        if g.expand:
+            dWm = hx.wgrad(x2, d_r, Cout, Cin)
+            dbm = hx.colsum(d_r)
+            d_x = hx.linear(d_r, hx.wt(blk.proj_max_pool.weight), None, torch.float32)
+            extra = [dWm, dbm]
+        else:
+            d_x = d_r
+        dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True)
+        grads = [dg1, dbe1, dWqkv, dbqkv, dWp, dbp] + pool_grads + [dg2, dbe2, dW1, db1, dW2, db2] + extra
+        return (d_x.view(B, N, Cin), None, None, None, None, None) + tuple(grads)
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, b, mask, hx):
+        L = hx.L
+        B, N, C = x.shape
+        x = x.contiguous()
+        nch = (N + 31) // 32
+        ws = torch.empty(B * nch * C, dtype=torch.float32, device=x.device)
+        eps = hx.m.norm.eps
+        _hip.check(L.mvit_head_ln_partial(_hip.ptr(x), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(ws), B, N, C, eps, _st()), "head1")
+        z = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        logits = torch.empty(B, w.shape[0], dtype=torch.float32, device=x.device)
+        _hip.check(L.mvit_head_project_train(_hip.ptr(ws), _hip.ptr(w), _hip.ptr(b), _hip.ptr(mask), _hip.ptr(z), _hip.ptr(logits), B, N,
+                                             nch, C, w.shape[0], _st()), "head2")
+        ctx.hx = hx
+        ctx.saved = (x, z, mask)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        hx = ctx.hx
+        L, m = hx.L, hx.m
+        x, z, mask = ctx.saved
+        ctx.saved = None
+        B, N, C = x.shape
+        dl = dl.contiguous().float()
+        ncls = dl.shape[1]
+        dW = torch.empty(ncls, C, dtype=torch.float32, device=x.device)
+        db = torch.empty(ncls, dtype=torch.float32, device=x.device)
+        dz = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        _hip.check(L.mvit_head_bwd(_hip.ptr(dl), _hip.ptr(z), _hip.ptr(m.head.projection.weight), _hip.ptr(mask), _hip.ptr(dW),
+                                   _hip.ptr(db), _hip.ptr(dz), B, C, ncls, 0, _st()), "head_bwd")
+        dx = torch.empty(B * N, C, dtype=torch.float32, device=x.device)
+        dg, dbe = hx.ln_bwd(x.view(B * N, C), m.norm, dz, dx, False, rows_per_dy=N, dy_scale=1.0 / N)
+        return dx.view(B, N, C), dg, dbe, dW, db, None, None
+
+
+def forward_train(model, clip):
+    """Forward in training mode (drop-path + head dropout active when model.training); returns raw logits.
+    Builds the autograd graph when grad mode is on."""
+    hx = _Ctx(model)
+    clip = clip.contiguous().float()
+    B = clip.shape[0]
+    dev = clip.device
+    assert list(clip.shape[2:]) == model.input_dims and clip.shape[1] == 3, "clip shape %s" % (tuple(clip.shape),)
+    pe = model.patch_embed.proj
+    x = _StemFn.apply(clip, pe.weight, pe.bias, model.pos_embed_spatial, model.pos_embed_temporal, hx)
+    for g, blk in zip(model.geoms, model.blocks):
+        dp1 = dp2 = None
+        if model.training and g.drop_path > 0.0:
+            keep = 1.0 - g.drop_path                       # common.py:46-59: one draw per sample per call
+            dp1 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
+            dp2 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
+        x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
+    mask = None
+    if model.training and model.head_dropout > 0.0:
+        p = model.head_dropout                             # head_helper.py:410-411
+        mask = (torch.rand(B, x.shape[2], device=dev) >= p).float() / (1.0 - p)
+    hp = model.head.projection
+    return _HeadFn.apply(x, model.norm.weight, model.norm.bias, hp.weight, hp.bias, mask, hx)
 
 
 def forward_with_grad(model, clip, return_logits=False):
-    raise NotImplementedError(
-        "MViT (HIP path): backward kernels are not built yet; run forward under torch.no_grad() "
-        "(inference / parity / forward benchmark). No eager fallback is provided on purpose.")
+    logits = forward_train(model, clip)
+    if return_logits:
+        return torch.softmax(logits, 1), logits
+    if model.training and not model.use_act_in_train:
+        return logits
+    return torch.softmax(logits, dim=1)      # eval-mode call with grad enabled: head act as in head_helper.py:415-416

@@ -24,7 +24,8 @@ __device__ __forceinline__ int kslab_off(int row, int chunk) {
 template <bool ADD_Q>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                             const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                            int heads, int Lq, int Lk, float scale_log2e) {
+                                                            float* __restrict__ LSE, int heads, int Lq, int Lk,
+                                                            float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char smem[2 * A_KT * A_ROWB];
     char* sK = smem;
     char* sV = smem + A_KT * A_ROWB;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     // ---- epilogue: normalise, + q residual, store [b][q][g*96 + d] -------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if (LSE && q_ok && h == 0) LSE[(int64_t)bh * Lq + qi] = m_run * scale_log2e + __builtin_amdgcn_logf(l_tot);  // log2 domain
     if (q_ok) {
         const int C = heads * 96;
         bf16_t* orow = O + ((int64_t)b * Lq + qi) * C + g * 96;
@@ -203,8 +205,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------------
 #define F_KT 32
 __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ Q, const float* __restrict__ Kt,
-                                                           const float* __restrict__ V, float* __restrict__ O, int heads,
-                                                           int Lq, int Lk, float scale, int add_q) {
+                                                           const float* __restrict__ V, float* __restrict__ O,
+                                                           float* __restrict__ LSE, int heads, int Lq, int Lk, float scale,
+                                                           int add_q) {
     __shared__ __attribute__((aligned(16))) float sK[F_KT * 96];
     __shared__ __attribute__((aligned(16))) float sV[F_KT * 96];
     const int bh = blockIdx.y;
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
     }
     if (q_ok) {
         const float inv = 1.0f / l_run;
+        if (LSE) LSE[(int64_t)bh * Lq + qi] = (m_run + logf(l_run)) * 1.44269504088896340736f;   // log2 units
         float* orow = O + ((int64_t)b * Lq + qi) * (heads * 96) + g * 96;
 #pragma unroll
         for (int d = 0; d < 96; d += 4) {
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
     }
 }
 
-extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int heads, int Lq,
-                                  int Lk, float scale, int add_q, int act_dtype, void* stream) {
+extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
+                                  int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
@@ -292,14 +296,14 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
         const float sl2 = scale * 1.44269504088896340736f;
         if (add_q)
             hipLaunchKernelGGL((attn_fwd_bf16_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, heads, Lq, Lk, sl2);
+                               (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
         else
             hipLaunchKernelGGL((attn_fwd_bf16_kernel<false>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, heads, Lq, Lk, sl2);
+                               (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
     } else if (act_dtype == MVIT_F32) {
         dim3 grid((Lq + 127) / 128, B * heads);
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(128), 0, st, (const float*)q, (const float*)k, (const float*)v,
-                           (float*)out, heads, Lq, Lk, scale, add_q);
+                           (float*)out, lse, heads, Lq, Lk, scale, add_q);
     } else {
         return MVIT_EDTYPE;
     }

@@ -1,0 +1,553 @@
+// Backward of the fused pooled attention (head_dim 96), recompute-from-LSE, no score matrix, NO float atomics:
+//   delta[q]  = sum_d dO[q][d] * O_attn[q][d]                               (attn_bwd_delta_kernel)
+//   pass A    : one wave = 32 queries, loops over 64-key tiles:  dQ  = scale * sum_k dS[q][k] K[k]   (+ dO if the
+//               forward added the pooled-q residual)
+//   pass B    : one wave = 32 keys, loops over 64-query tiles:   dV  = sum_q P[q][k] dO[q],  dK = scale * sum_q dS[q][k] Q[q]
+//   with P = exp2(score*scale*log2e - LSE2[q]),  dS = P * (dP - delta[q]),  dP = dO . V^T.
+// Both passes are the forward kernel's skeleton (resident operand as MFMA B fragments in registers, streamed tiles in
+// LDS, accumulator tile reused directly as the B operand of the second product); recomputing S/dP in both passes
+// costs 7 instead of 5 matrix products but keeps the pass deterministic and free of the 1.3 TB/s atomic ceiling.
+#include "common.h"
+
+#define B_T 64            // streamed rows per tile
+#define B_ROWB 192
+typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+
+__device__ __forceinline__ int rot_off(int row, int chunk) {   // rotation-swizzled [rows][96] bf16 image (row reads)
+    int p = chunk + ((row >> 2) & 3);
+    p = p >= 12 ? p - 12 : p;
+    return row * B_ROWB + p * 16;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {      // two transposed 4x16 reads -> one 8-element fragment
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(p + 8 * B_ROWB));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    uint4 u = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    return *reinterpret_cast<bf16x8*>(&u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta: 8 lanes per (b, g, q), 12 channels each.  dO, O: [B][Lq][heads*96]; Q: [B][heads][Lq][96].
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const T* __restrict__ dO, const T* __restrict__ O,
+                                                             const T* __restrict__ Q, float* __restrict__ delta, int B,
+                                                             int heads, int Lq, int add_q) {
+    const int64_t total = (int64_t)B * heads * Lq;
+    const int j = threadIdx.x & 7;
+    for (int64_t it0 = (int64_t)blockIdx.x * 32; it0 < total; it0 += (int64_t)gridDim.x * 32) {
+        const int64_t it = it0 + (threadIdx.x >> 3);
+        const bool ok = it < total;
+        const int64_t itc = ok ? it : total - 1;
+        const int q = (int)(itc % Lq);
+        const int g = (int)((itc / Lq) % heads);
+        const int b = (int)(itc / ((int64_t)Lq * heads));
+        const int64_t orow = ((int64_t)b * Lq + q) * heads * 96 + g * 96 + 12 * j;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 12; e += 4) {
+            const float4 d = load4(dO + orow + e);
+            float4 o = load4(O + orow + e);
+            if (add_q) {
+                const float4 qq = load4(Q + itc * 96 + 12 * j + e);
+                o.x -= qq.x; o.y -= qq.y; o.z -= qq.z; o.w -= qq.w;
+            }
+            s += d.x * o.x + d.y * o.y + d.z * o.z + d.w * o.w;
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (ok && j == 0) delta[it] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass A (bf16 MFMA): dQ.   grid (ceil(Lq/128), B*heads), 4 waves x 32 queries.
+// ------------------------------------------------------------------------------------------------
+template <bool ADD_Q>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
+                                                          float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * B_T * B_ROWB];
+    char* sK = smem;                       // rotation image of K (row reads)
+    char* sKp = smem + B_T * B_ROWB;       // plain image of K (transposed reads)
+    char* sV = smem + 2 * B_T * B_ROWB;    // rotation image of V (row reads)
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    int qi = blockIdx.x * 128 + wave * 32 + r;
+    const bool q_ok = qi < Lq;
+    qi = q_ok ? qi : Lq - 1;
+    const int C = heads * 96;
+    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
+    const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
+    const bf16_t* dOrow = dO + ((int64_t)b * Lq + qi) * C + g * 96;
+    bf16x8 qf[6], dof[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(dOrow + 16 * ks + 8 * h);
+    }
+    const float lse = LSE[(int64_t)bh * Lq + qi];
+    const float dlt = delta[(int64_t)bh * Lq + qi];
+
+    int s_row[3], s_chk[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        s_row[i] = c / 12;
+        s_chk[i] = c - s_row[i] * 12;
+    }
+    uint4 rk[3], rv[3];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int key = k0 + s_row[i];
+            rk[i] = make_uint4(0, 0, 0, 0);
+            rv[i] = rk[i];
+            if (key < Lk) {
+                rk[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * 96 + 8 * s_chk[i]);
+                rv[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * 96 + 8 * s_chk[i]);
+            }
+        }
+    };
+    int koff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        int p = 2 * ks + h + ((r >> 2) & 3);
+        p = p >= 12 ? p - 12 : p;
+        koff[ks] = p * 16;
+    }
+    const int i16 = lane & 15, gi = lane >> 4;
+    const int t_lane = (4 * h + (i16 >> 2)) * B_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+
+    f32x16 dq[3];
+#pragma unroll
+    for (int db = 0; db < 3; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+
+    const int nkt = (Lk + B_T - 1) / B_T;
+    gload(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<uint4*>(sK + rot_off(s_row[i], s_chk[i])) = rk[i];
+            *reinterpret_cast<uint4*>(sKp + s_row[i] * B_ROWB + s_chk[i] * 16) = rk[i];
+            *reinterpret_cast<uint4*>(sV + rot_off(s_row[i], s_chk[i])) = rv[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) gload((kt + 1) * B_T);
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+            const char* kr = sK + (32 * kb + r) * B_ROWB;
+            const char* vr = sV + (32 * kb + r) * B_ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + koff[ks]);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vr + koff[ks]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);      // S^T  = K . Q^T
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);   // dP^T = V . dO^T
+            }
+        }
+        const int kbase = kt * B_T;
+        const bool tail = kbase + B_T > Lk;
+        bf16x8 dsf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float dsv[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int i = 8 * sh + jj;
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2e, -lse));
+                    if (tail) {
+                        const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        p = key < Lk ? p : 0.f;
+                    }
+                    dsv[jj] = p * (dp[kb][i] - dlt);
+                }
+                dsf[2 * kb + sh] = pack8(dsv);
+            }
+        // dQ^T += K^T . dS^T
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16)
+#pragma unroll
+            for (int db = 0; db < 3; ++db) {
+                const bf16x8 kf = tr_frag(sKp + t_lane + s16 * 16 * B_ROWB + db * 64);
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf[s16], dq[db], 0, 0, 0);
+            }
+    }
+    if (q_ok) {
+        bf16_t* orow = dQ + ((int64_t)bh * Lq + qi) * 96;
+#pragma unroll
+        for (int db = 0; db < 3; ++db)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int d = 32 * db + 8 * i4 + 4 * h;
+                float4 v = make_float4(dq[db][4 * i4] * scale, dq[db][4 * i4 + 1] * scale, dq[db][4 * i4 + 2] * scale,
+                                       dq[db][4 * i4 + 3] * scale);
+                if (ADD_Q) {
+                    const float4 dd = load4(dOrow + d);
+                    v.x += dd.x; v.y += dd.y; v.z += dd.z; v.w += dd.w;
+                }
+                store4(orow + d, v);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B (bf16 MFMA): dK, dV.   grid (ceil(Lk/128), B*heads), 4 waves x 32 keys; streams 64-query tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int heads,
+                                                           int Lq, int Lk, float scale, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * B_T * B_ROWB + 2 * B_T * 4];
+    char* sQ = smem;                        // rotation image (row reads)
+    char* sQp = smem + B_T * B_ROWB;        // plain image (transposed reads)
+    char* sD = smem + 2 * B_T * B_ROWB;     // dO rotation image
+    char* sDp = smem + 3 * B_T * B_ROWB;    // dO plain image
+    float* sL = reinterpret_cast<float*>(smem + 4 * B_T * B_ROWB);   // lse[64], delta[64]
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    int ki = blockIdx.x * 128 + wave * 32 + r;
+    const bool k_ok = ki < Lk;
+    ki = k_ok ? ki : Lk - 1;
+    const int C = heads * 96;
+    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
+    const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
+    const bf16_t* dOb = dO + (int64_t)b * Lq * C + g * 96;
+    bf16x8 kf[6], vf[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)ki * 96 + 16 * ks + 8 * h);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)ki * 96 + 16 * ks + 8 * h);
+    }
+    int s_row[3], s_chk[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        s_row[i] = c / 12;
+        s_chk[i] = c - s_row[i] * 12;
+    }
+    uint4 rq[3], rd[3];
+    float rl = 0.f;
+    auto gload = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = q0 + s_row[i];
+            rq[i] = make_uint4(0, 0, 0, 0);
+            rd[i] = rq[i];
+            if (q < Lq) {
+                rq[i] = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * 96 + 8 * s_chk[i]);
+                rd[i] = *reinterpret_cast<const uint4*>(dOb + (int64_t)q * C + 8 * s_chk[i]);
+            }
+        }
+        if (tid < 128) {
+            const int q = q0 + (tid & 63);
+            // invalid queries: lse = +inf -> P = exp2(-inf) = 0
+            rl = q < Lq ? (tid < 64 ? LSE[(int64_t)bh * Lq + q] : delta[(int64_t)bh * Lq + q]) : (tid < 64 ? INFINITY : 0.f);
+        }
+    };
+    int roff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        int p = 2 * ks + h + ((r >> 2) & 3);
+        p = p >= 12 ? p - 12 : p;
+        roff[ks] = p * 16;
+    }
+    const int i16 = lane & 15, gi = lane >> 4;
+    const int t_lane = (4 * h + (i16 >> 2)) * B_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+
+    f32x16 dk[3], dv[3];
+#pragma unroll
+    for (int db = 0; db < 3; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+
+    const int nqt = (Lq + B_T - 1) / B_T;
+    gload(0);
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<uint4*>(sQ + rot_off(s_row[i], s_chk[i])) = rq[i];
+            *reinterpret_cast<uint4*>(sQp + s_row[i] * B_ROWB + s_chk[i] * 16) = rq[i];
+            *reinterpret_cast<uint4*>(sD + rot_off(s_row[i], s_chk[i])) = rd[i];
+            *reinterpret_cast<uint4*>(sDp + s_row[i] * B_ROWB + s_chk[i] * 16) = rd[i];
+        }
+        if (tid < 128) sL[tid] = rl;
+        __syncthreads();
+        if (qt + 1 < nqt) gload((qt + 1) * B_T);
+        // S = Q . K^T  and dP = dO . V^T   (rows = queries in registers, column = this lane's key)
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
+            const char* qr = sQ + (32 * qb + r) * B_ROWB;
+            const char* dr = sD + (32 * qb + r) * B_ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qr + roff[ks]);
+                const bf16x8 df = *reinterpret_cast<const bf16x8*>(dr + roff[ks]);
+                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s[qb], 0, 0, 0);
+                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp[qb], 0, 0, 0);
+            }
+        }
+        bf16x8 pf[4], dsf[4];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int g4 = 0; g4 < 2; ++g4) {
+                    // rows 32qb + 8*(2sh+g4) + 4h + 0..3
+                    const int q4 = 32 * qb + 8 * (2 * sh + g4) + 4 * h;
+                    const float4 l4 = *reinterpret_cast<const float4*>(sL + q4);
+                    const float4 d4 = *reinterpret_cast<const float4*>(sL + 64 + q4);
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+                    const float ds4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 8 * sh + 4 * g4 + e;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][i], scale_log2e, -ls[e]));
+                        pv[4 * g4 + e] = p;
+                        dsv[4 * g4 + e] = p * (dp[qb][i] - ds4[e]);
+                    }
+                }
+                pf[2 * qb + sh] = pack8(pv);
+                dsf[2 * qb + sh] = pack8(dsv);
+            }
+        // dV^T += dO^T . P ;  dK^T += Q^T . dS
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16)
+#pragma unroll
+            for (int db = 0; db < 3; ++db) {
+                const bf16x8 dof = tr_frag(sDp + t_lane + s16 * 16 * B_ROWB + db * 64);
+                const bf16x8 qtf = tr_frag(sQp + t_lane + s16 * 16 * B_ROWB + db * 64);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf[s16], dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[s16], dk[db], 0, 0, 0);
+            }
+    }
+    if (k_ok) {
+        bf16_t* krow = dK + ((int64_t)bh * Lk + ki) * 96;
+        bf16_t* vrow = dV + ((int64_t)bh * Lk + ki) * 96;
+#pragma unroll
+        for (int db = 0; db < 3; ++db)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int d = 32 * db + 8 * i4 + 4 * h;
+                store4(krow + d, make_float4(dk[db][4 * i4] * scale, dk[db][4 * i4 + 1] * scale, dk[db][4 * i4 + 2] * scale,
+                                             dk[db][4 * i4 + 3] * scale));
+                store4(vrow + d, make_float4(dv[db][4 * i4], dv[db][4 * i4 + 1], dv[db][4 * i4 + 2], dv[db][4 * i4 + 3]));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32 passes (parity path): 4 lanes per row, 24 channels each; streamed tiles of 32 rows in LDS.
+// ------------------------------------------------------------------------------------------------
+#define F_T 32
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ Q, const float* __restrict__ Kt,
+                                                              const float* __restrict__ V, const float* __restrict__ dO,
+                                                              const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                              float* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
+                                                              int add_q) {
+    __shared__ __attribute__((aligned(16))) float sK[F_T * 96];
+    __shared__ __attribute__((aligned(16))) float sV[F_T * 96];
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int j = threadIdx.x & 3;
+    int qi = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool q_ok = qi < Lq;
+    qi = q_ok ? qi : Lq - 1;
+    const int C = heads * 96;
+    float q[24], d[24], acc[24];
+    const float* qrow = Q + ((int64_t)bh * Lq + qi) * 96 + 24 * j;
+    const float* drow = dO + ((int64_t)b * Lq + qi) * C + g * 96 + 24 * j;
+#pragma unroll
+    for (int e = 0; e < 24; ++e) { q[e] = qrow[e]; d[e] = drow[e]; acc[e] = 0.f; }
+    const float lse = LSE[(int64_t)bh * Lq + qi] * 0.69314718055994530942f;   // stored in log2 units
+    const float dlt = delta[(int64_t)bh * Lq + qi];
+    const float* Kb = Kt + (int64_t)bh * Lk * 96;
+    const float* Vb = V + (int64_t)bh * Lk * 96;
+    for (int k0 = 0; k0 < Lk; k0 += F_T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F_T * 24; i += 256) {
+            const int row = i / 24, c4 = i - row * 24;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (k0 + row < Lk) {
+                kv = load4(Kb + (int64_t)(k0 + row) * 96 + 4 * c4);
+                vv = load4(Vb + (int64_t)(k0 + row) * 96 + 4 * c4);
+            }
+            *reinterpret_cast<float4*>(sK + row * 96 + 4 * c4) = kv;
+            *reinterpret_cast<float4*>(sV + row * 96 + 4 * c4) = vv;
+        }
+        __syncthreads();
+        const int nk = min(F_T, Lk - k0);
+        for (int kk = 0; kk < nk; ++kk) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < 24; ++e) {
+                s = fmaf(q[e], sK[kk * 96 + 24 * j + e], s);
+                dp = fmaf(d[e], sV[kk * 96 + 24 * j + e], dp);
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+            dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
+            const float p = expf(s * scale - lse);
+            const float ds = p * (dp - dlt);
+#pragma unroll
+            for (int e = 0; e < 24; ++e) acc[e] = fmaf(ds, sK[kk * 96 + 24 * j + e], acc[e]);
+        }
+    }
+    if (q_ok) {
+        float* o = dQ + ((int64_t)bh * Lq + qi) * 96 + 24 * j;
+#pragma unroll
+        for (int e = 0; e < 24; ++e) o[e] = acc[e] * scale + (add_q ? d[e] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ Q, const float* __restrict__ Kt,
+                                                               const float* __restrict__ V, const float* __restrict__ dO,
+                                                               const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                               float* __restrict__ dK, float* __restrict__ dV, int heads,
+                                                               int Lq, int Lk, float scale) {
+    __shared__ __attribute__((aligned(16))) float sQ[F_T * 96];
+    __shared__ __attribute__((aligned(16))) float sD[F_T * 96];
+    __shared__ float sL[2 * F_T];
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int j = threadIdx.x & 3;
+    int ki = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool k_ok = ki < Lk;
+    ki = k_ok ? ki : Lk - 1;
+    const int C = heads * 96;
+    float k[24], v[24], ak[24], av[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) {
+        k[e] = Kt[((int64_t)bh * Lk + ki) * 96 + 24 * j + e];
+        v[e] = V[((int64_t)bh * Lk + ki) * 96 + 24 * j + e];
+        ak[e] = 0.f; av[e] = 0.f;
+    }
+    const float* Qb = Q + (int64_t)bh * Lq * 96;
+    const float* dOb = dO + (int64_t)b * Lq * C + g * 96;
+    for (int q0 = 0; q0 < Lq; q0 += F_T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < F_T * 24; i += 256) {
+            const int row = i / 24, c4 = i - row * 24;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), dv4 = qv;
+            if (q0 + row < Lq) {
+                qv = load4(Qb + (int64_t)(q0 + row) * 96 + 4 * c4);
+                dv4 = load4(dOb + (int64_t)(q0 + row) * C + 4 * c4);
+            }
+            *reinterpret_cast<float4*>(sQ + row * 96 + 4 * c4) = qv;
+            *reinterpret_cast<float4*>(sD + row * 96 + 4 * c4) = dv4;
+        }
+        if (threadIdx.x < 2 * F_T) {
+            const int qq = q0 + (threadIdx.x & (F_T - 1));
+            sL[threadIdx.x] = qq < Lq ? (threadIdx.x < F_T ? LSE[(int64_t)bh * Lq + qq] * 0.69314718055994530942f
+                                                           : delta[(int64_t)bh * Lq + qq])
+                                      : (threadIdx.x < F_T ? INFINITY : 0.f);
+        }
+        __syncthreads();
+        const int nq = min(F_T, Lq - q0);
+        for (int qq = 0; qq < nq; ++qq) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < 24; ++e) {
+                s = fmaf(k[e], sQ[qq * 96 + 24 * j + e], s);
+                dp = fmaf(v[e], sD[qq * 96 + 24 * j + e], dp);
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+            dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
+            const float p = expf(s * scale - sL[qq]);
+            const float ds = p * (dp - sL[F_T + qq]);
+#pragma unroll
+            for (int e = 0; e < 24; ++e) {
+                av[e] = fmaf(p, sD[qq * 96 + 24 * j + e], av[e]);
+                ak[e] = fmaf(ds, sQ[qq * 96 + 24 * j + e], ak[e]);
+            }
+        }
+    }
+    if (k_ok) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e) {
+            dK[((int64_t)bh * Lk + ki) * 96 + 24 * j + e] = ak[e] * scale;
+            dV[((int64_t)bh * Lk + ki) * 96 + 24 * j + e] = av[e];
+        }
+    }
+}
+
+extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq) {
+    return (int64_t)B * heads * Lq * (int64_t)sizeof(float);
+}
+
+// q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.
+// dq [B][heads][Lq][96], dk/dv [B][heads][Lk][96] (act-typed).  workspace: fp32 [B*heads*Lq] (delta).
+extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                                  const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
+                                  int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream) {
+    if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !workspace || B <= 0 || heads <= 0 || Lq <= 0 ||
+        Lk <= 0)
+        return MVIT_EINVAL;
+    if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int64_t rows = (int64_t)B * heads * Lq;
+    int64_t dblocks = (rows + 31) / 32;
+    if (dblocks > 16384) dblocks = 16384;
+    const float sl2 = scale * 1.44269504088896340736f;
+    if (act_dtype == MVIT_BF16) {
+        hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t>), dim3((unsigned)dblocks), dim3(256), 0, st, (const bf16_t*)dout,
+                           (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
+        MVIT_LAUNCH_CHECK();
+        dim3 gq((Lq + 127) / 128, B * heads);
+        if (add_q)
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
+        else
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
+        MVIT_LAUNCH_CHECK();
+        dim3 gk((Lk + 127) / 128, B * heads);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                           (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, heads, Lq, Lk, scale, sl2);
+        MVIT_LAUNCH_CHECK();
+        return MVIT_OK;
+    }
+    if (act_dtype != MVIT_F32) return MVIT_EDTYPE;
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<float>), dim3((unsigned)dblocks), dim3(256), 0, st, (const float*)dout,
+                       (const float*)out, (const float*)q, workspace, B, heads, Lq, add_q);
+    MVIT_LAUNCH_CHECK();
+    dim3 gq((Lq + 63) / 64, B * heads);
+    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel, gq, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
+                       (const float*)dout, lse, workspace, (float*)dq, heads, Lq, Lk, scale, add_q);
+    MVIT_LAUNCH_CHECK();
+    dim3 gk((Lk + 63) / 64, B * heads);
+    hipLaunchKernelGGL(attn_bwd_dkv_f32_kernel, gk, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v,
+                       (const float*)dout, lse, workspace, (float*)dk, (float*)dv, heads, Lq, Lk, scale);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}

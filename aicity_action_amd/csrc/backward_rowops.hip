@@ -1,0 +1,428 @@
+// Backward / training-step row kernels (HBM-bound): LayerNorm bwd, GELU fwd/bwd, skip max-pool bwd, column sums
+// (bias gradients), soft-target cross entropy, global grad-norm, AdamW.  All reductions are two-stage and
+// deterministic (no float atomics) unless noted.
+#include "common.h"
+
+template <int LPR>
+__device__ __forceinline__ float gsum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm backward.  x fp32 [rows][C] (forward input, stats recomputed), dy TDY [rows][C] or, in broadcast mode,
+// dy fp32 [rows/rows_per_dy][C] scaled by dy_scale (head: d(mean over tokens)).
+// dx fp32 [rows][C] (+= if accumulate).  part: [gridDim.x][2][C] partial dgamma / dbeta.
+// ----------------------------------------------------------------------------------------------
+template <int C, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const TDY* __restrict__ dy, int64_t rows_per_dy, float dy_scale,
+                                                     float* __restrict__ dx, int accumulate, float* __restrict__ part,
+                                                     int64_t rows, float eps) {
+    constexpr int LPR = C / 12;
+    constexpr int RPB = 256 / LPR;
+    __shared__ float red[RPB][2 * C];
+    const int lir = threadIdx.x % LPR, rib = threadIdx.x / LPR;
+    float4 g[3], ag[3], ab[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        g[i] = load4(gamma + 4 * (lir + LPR * i));
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < rows; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t r = r0 + rib;
+        const bool ok = r < rows;
+        float4 v[3], d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            d[i] = v[i];
+            if (ok) {
+                v[i] = load4(x + r * C + 4 * (lir + LPR * i));
+                d[i] = load4(dy + (r / rows_per_dy) * C + 4 * (lir + LPR * i));
+                d[i].x *= dy_scale; d[i].y *= dy_scale; d[i].z *= dy_scale; d[i].w *= dy_scale;
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = gsum<LPR>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(gsum<LPR>(q) * (1.0f / C) + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;   // xhat
+            ag[i].x += d[i].x * v[i].x; ag[i].y += d[i].y * v[i].y; ag[i].z += d[i].z * v[i].z; ag[i].w += d[i].w * v[i].w;
+            ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+            d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;   // g*dy
+            c1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+            c2 += (d[i].x * v[i].x + d[i].y * v[i].y) + (d[i].z * v[i].z + d[i].w * v[i].w);
+        }
+        c1 = gsum<LPR>(c1) * (1.0f / C);
+        c2 = gsum<LPR>(c2) * (1.0f / C);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float* p = dx + r * C + 4 * (lir + LPR * i);
+                float4 o;
+                o.x = rstd * (d[i].x - c1 - v[i].x * c2);
+                o.y = rstd * (d[i].y - c1 - v[i].y * c2);
+                o.z = rstd * (d[i].z - c1 - v[i].z * c2);
+                o.w = rstd * (d[i].w - c1 - v[i].w * c2);
+                if (accumulate) {
+                    const float4 old = load4(p);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                store4(p, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        *reinterpret_cast<float4*>(&red[rib][4 * (lir + LPR * i)]) = ag[i];
+        *reinterpret_cast<float4*>(&red[rib][C + 4 * (lir + LPR * i)]) = ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) s += red[r][c];
+        part[(int64_t)blockIdx.x * 2 * C + c] = s;
+    }
+}
+
+// out[j] (+)= sum_b part[b][j]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
+                                                              float* __restrict__ out_a, float* __restrict__ out_b,
+                                                              int split, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * width + j];
+    float* o = (j < split) ? out_a + j : out_b + (j - split);
+    *o = accumulate ? *o + s : s;
+}
+
+#define LN_BWD_MAXBLK 1024
+extern "C" int64_t mvit_layernorm_bwd_workspace_bytes(int C) { return (int64_t)LN_BWD_MAXBLK * 2 * C * sizeof(float); }
+
+template <int C, typename TDY>
+static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int64_t rpd, float dys, float* dx, int acc,
+                         float* dgamma, float* dbeta, int acc_param, float* ws, int64_t rows, float eps, hipStream_t st) {
+    constexpr int RPB = 256 / (C / 12);
+    int64_t blocks = (rows + RPB - 1) / RPB;
+    if (blocks > LN_BWD_MAXBLK) blocks = LN_BWD_MAXBLK;
+    hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
+                       dx, acc, ws, rows, eps);
+    MVIT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, (int)blocks, 2 * C, dgamma,
+                       dbeta, C, acc_param);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
+extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+                                  float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
+                                  int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || rows_per_dy <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+#define LNB(CC)                                                                                                      \
+    case CC:                                                                                                         \
+        if (dy_dtype == MVIT_F32)                                                                                    \
+            return launch_ln_bwd<CC, float>(x, gamma, dy, rows_per_dy, dy_scale, dx, accumulate_dx, dgamma, dbeta,    \
+                                            accumulate_param, workspace, rows, eps, st);                             \
+        if (dy_dtype == MVIT_BF16 && rows_per_dy == 1)                                                               \
+            return launch_ln_bwd<CC, bf16_t>(x, gamma, dy, 1, dy_scale, dx, accumulate_dx, dgamma, dbeta,             \
+                                             accumulate_param, workspace, rows, eps, st);                            \
+        return MVIT_EDTYPE;
+    switch (C) {
+        LNB(96) LNB(192) LNB(384) LNB(768)
+        default: return MVIT_EUNSUPPORTED;
+    }
+#undef LNB
+}
+
+// ----------------------------------------------------------------------------------------------
+// GELU (exact erf) forward / backward, elementwise, n % 4 == 0.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = load4(x + 4 * i);
+        v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        store4(y + 4 * i, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                       int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = load4(x + 4 * i);
+        float4 d = load4(dy + 4 * i);
+        d.x *= gelu_grad(v.x); d.y *= gelu_grad(v.y); d.z *= gelu_grad(v.z); d.w *= gelu_grad(v.w);
+        store4(dx + 4 * i, d);
+    }
+}
+
+static unsigned ew_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+extern "C" int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream) {
+    if (!x || !y || n < 0 || (n & 3)) return MVIT_EINVAL;
+    if (n == 0) return MVIT_OK;
+    if (act_dtype == MVIT_F32)
+        hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, n / 4);
+    else if (act_dtype == MVIT_BF16)
+        hipLaunchKernelGGL((gelu_fwd_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, n / 4);
+    else
+        return MVIT_EDTYPE;
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream) {
+    if (!x || !dy || !dx || n < 0 || (n & 3)) return MVIT_EINVAL;
+    if (n == 0) return MVIT_OK;
+    if (act_dtype == MVIT_F32)
+        hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)dx, n / 4);
+    else if (act_dtype == MVIT_BF16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 4);
+    else
+        return MVIT_EDTYPE;
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Skip max-pool backward (gather form, deterministic): dx[in] = sum over the <=4 windows that contain `in` and
+// whose FIRST maximum (scan order dy,dx as ATen) is `in`.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_skip_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int BT, int H, int W, int Ho, int Wo,
+                                                               int C4) {
+    const int64_t total = (int64_t)BT * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t tok = i / C4;
+        const int xi = (int)(tok % W); tok /= W;
+        const int yi = (int)(tok % H);
+        const int64_t bt = tok / H;
+        const float4 me = load4(x + i * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows (yo,xo) with 2*yo-1 <= yi <= 2*yo+1
+        for (int yo = (yi) / 2; yo <= (yi + 1) / 2; ++yo) {
+            if (yo < 0 || yo >= Ho) continue;
+            for (int xo = (xi) / 2; xo <= (xi + 1) / 2; ++xo) {
+                if (xo < 0 || xo >= Wo) continue;
+                // is `me` the first maximum of this window, per channel?
+                float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                int4 bidx = make_int4(-1, -1, -1, -1);
+                int myidx = -1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = 2 * yo + ky - 1;
+                    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = 2 * xo + kx - 1;
+                        if (xx < 0 || xx >= W) continue;
+                        const int widx = ky * 3 + kx;
+                        if (yy == yi && xx == xi) myidx = widx;
+                        const float4 v = load4(x + (((bt * H + yy) * W + xx) * C4 + c4) * 4);
+                        if (v.x > best.x) { best.x = v.x; bidx.x = widx; }
+                        if (v.y > best.y) { best.y = v.y; bidx.y = widx; }
+                        if (v.z > best.z) { best.z = v.z; bidx.z = widx; }
+                        if (v.w > best.w) { best.w = v.w; bidx.w = widx; }
+                    }
+                }
+                const float4 g = load4(dy + (((bt * Ho + yo) * Wo + xo) * C4 + c4) * 4);
+                if (bidx.x == myidx) acc.x += g.x;
+                if (bidx.y == myidx) acc.y += g.y;
+                if (bidx.z == myidx) acc.z += g.z;
+                if (bidx.w == myidx) acc.w += g.w;
+            }
+        }
+        (void)me;
+        store4(dx + i * 4, acc);
+    }
+}
+
+extern "C" int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int T, int H, int W, int C,
+                                     void* stream) {
+    if (!x || !dy || !dx || B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MVIT_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)B * T * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_skip_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), x, dy, dx, B * T, H, W,
+                       Ho, Wo, C / 4);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Column sums: out[n] (+)= scale-weighted sum over rows of a[M][N]  (bias gradients; two-stage).
+// ----------------------------------------------------------------------------------------------
+#define CS_MAXBLK 512
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t M, int N,
+                                                             const float* __restrict__ row_scale, int64_t rps,
+                                                             float* __restrict__ part) {
+    // thread -> 4 consecutive columns; block strides over rows
+    const int n4 = N / 4;
+    for (int c = threadIdx.x; c < n4; c += 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
+            const float4 v = load4(a + m * N + 4 * c);
+            const float sc = row_scale ? row_scale[m / rps] : 1.f;
+            s.x += sc * v.x; s.y += sc * v.y; s.z += sc * v.z; s.w += sc * v.w;
+        }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * N + 4 * c) = s;
+    }
+}
+
+extern "C" int64_t mvit_colsum_workspace_bytes(int N) { return (int64_t)CS_MAXBLK * N * sizeof(float); }
+
+extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_scale, int64_t rows_per_scale,
+                           float* out, int accumulate, float* workspace, void* stream) {
+    if (!a || !out || !workspace || M <= 0 || N <= 0 || (N & 3)) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int blocks = (int)(M < CS_MAXBLK ? M : CS_MAXBLK);
+    if (a_dtype == MVIT_F32)
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, M, N, row_scale, rows_per_scale, workspace);
+    else if (a_dtype == MVIT_BF16)
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, M, N, row_scale, rows_per_scale, workspace);
+    else
+        return MVIT_EDTYPE;
+    MVIT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, blocks, N, out, out, N, accumulate);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Soft-target cross entropy (slowfast/models/losses.py:133-142, reduction mean) forward + dlogits, B x ncls small.
+// ----------------------------------------------------------------------------------------------
+__global__ void softce_kernel(const float* __restrict__ logits, const float* __restrict__ y, float* __restrict__ loss,
+                              float* __restrict__ dlogits, int B, int ncls, float grad_scale) {
+    extern __shared__ float sm[];
+    float* per = sm;  // [B]
+    const int b = threadIdx.x;
+    if (b < B) {
+        const float* l = logits + (int64_t)b * ncls;
+        const float* t = y + (int64_t)b * ncls;
+        float m = -INFINITY;
+        for (int j = 0; j < ncls; ++j) m = fmaxf(m, l[j]);
+        float den = 0.f, ysum = 0.f;
+        for (int j = 0; j < ncls; ++j) { den += expf(l[j] - m); ysum += t[j]; }
+        const float lse = m + logf(den);
+        float acc = 0.f;
+        for (int j = 0; j < ncls; ++j) {
+            acc += -t[j] * (l[j] - lse);
+            if (dlogits) dlogits[(int64_t)b * ncls + j] = grad_scale * (expf(l[j] - lse) * ysum - t[j]) / (float)B;
+        }
+        per[b] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < B; ++i) s += per[i];
+        *loss = s / (float)B;
+    }
+}
+
+extern "C" int mvit_soft_ce(const float* logits, const float* labels, float* loss, float* dlogits, int B, int num_classes,
+                            float grad_scale, void* stream) {
+    if (!logits || !labels || !loss || B <= 0 || B > 1024 || num_classes <= 0) return MVIT_EINVAL;
+    hipLaunchKernelGGL(softce_kernel, dim3(1), dim3(((B + 63) / 64) * 64), B * sizeof(float), as_stream(stream), logits, labels,
+                       loss, dlogits, B, num_classes, grad_scale);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Multi-tensor helpers over a device table of (pointer, count) chunks: squared-norm partials and AdamW.
+// The host flattens the parameter list once into chunk descriptors (<= CHUNK elements each).
+// ----------------------------------------------------------------------------------------------
+struct MtChunk { float* p; float* g; float* m; float* v; int n; float wd; };
+
+__global__ __launch_bounds__(256) void sqnorm_chunks_kernel(const MtChunk* __restrict__ ch, float* __restrict__ part) {
+    __shared__ float red[4];
+    const MtChunk c = ch[blockIdx.x];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < c.n; i += 256) { const float g = c.g[i]; s += g * g; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// total = sqrt(sum part); coef = min(1, max_norm / (total + 1e-6))  (torch clip_grad_norm_ semantics); max_norm<=0: coef=1
+__global__ void gradnorm_finish_kernel(const float* __restrict__ part, int n, float max_norm, float* __restrict__ out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)part[i];
+        const float tot = (float)sqrt(s);
+        out2[0] = tot;
+        out2[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (tot + 1e-6f)) : 1.0f;
+    }
+}
+
+// AdamW, decoupled weight decay, bias correction (torch.optim.AdamW, amsgrad False); grads scaled by *coef (clip).
+__global__ __launch_bounds__(256) void adamw_chunks_kernel(const MtChunk* __restrict__ ch, const float* __restrict__ coef_ptr,
+                                                           float lr, float beta1, float beta2, float eps, float bc1,
+                                                           float bc2_sqrt) {
+    const MtChunk c = ch[blockIdx.x];
+    const float coef = coef_ptr ? coef_ptr[1] : 1.0f;
+    for (int i = threadIdx.x; i < c.n; i += 256) {
+        const float g = c.g[i] * coef;
+        float p = c.p[i] * (1.0f - lr * c.wd);
+        const float m = beta1 * c.m[i] + (1.0f - beta1) * g;
+        const float v = beta2 * c.v[i] + (1.0f - beta2) * g * g;
+        c.m[i] = m;
+        c.v[i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        p -= (lr / bc1) * (m / denom);
+        c.p[i] = p;
+    }
+}
+
+extern "C" int mvit_grad_norm(const void* chunk_table, int nchunks, float max_norm, float* partials, float* out2,
+                              void* stream) {
+    if (!chunk_table || !partials || !out2 || nchunks <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(sqnorm_chunks_kernel, dim3(nchunks), dim3(256), 0, st, (const MtChunk*)chunk_table, partials);
+    MVIT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(64), 0, st, partials, nchunks, max_norm, out2);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_adamw_step(const void* chunk_table, int nchunks, const float* norm_coef, float lr, float beta1,
+                               float beta2, float eps, int step, void* stream) {
+    if (!chunk_table || nchunks <= 0 || step <= 0) return MVIT_EINVAL;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream), (const MtChunk*)chunk_table, norm_coef,
+                       lr, beta1, beta2, eps, bc1, bc2s);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_mt_chunk_bytes(void) { return (int)sizeof(MtChunk); }

@@ -1,0 +1,208 @@
+// Weight gradients of the Linear layers:  dW[N][K] += sum_m dy[m][n] * a[m][k]   (a "TN" GEMM whose reduction
+// dimension is the huge token dimension M).
+//   * bf16 path: MFMA 32x32x16; one workgroup = a 96x96 tile of dW over a chunk of M.  Both operands have M
+//     as the MFMA k dimension, so both fragments are TRANSPOSED reads (ds_read_b64_tr_b16) of row-major
+//     [64 m][96] bf16 slabs; the four waves take one 16-row k-step of every slab each (9 MFMAs/wave/slab) and
+//     add their partial tiles to dW with fp32 atomics (128 B contiguous per half-wave; dW is tiny next to M).
+//   * fp32 path: exact VALU kernel (parity path).
+// dy may carry a per-sample drop-path factor (row_scale), applied while staging.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+
+#define WG_MCHUNK 1024
+#define WG_ROWB 192
+
+template <typename T>
+__device__ __forceinline__ uint4 stage8(const T* p, float sc);
+template <>
+__device__ __forceinline__ uint4 stage8<bf16_t>(const bf16_t* p, float sc) {
+    if (sc == 1.0f) return *reinterpret_cast<const uint4*>(p);
+    float4 lo, hi;
+    load8(p, lo, hi);
+    uint4 r;
+    r.x = pack_bf16x2(lo.x * sc, lo.y * sc); r.y = pack_bf16x2(lo.z * sc, lo.w * sc);
+    r.z = pack_bf16x2(hi.x * sc, hi.y * sc); r.w = pack_bf16x2(hi.z * sc, hi.w * sc);
+    return r;
+}
+template <>
+__device__ __forceinline__ uint4 stage8<float>(const float* p, float sc) {
+    float4 lo, hi;
+    load8(p, lo, hi);
+    uint4 r;
+    r.x = pack_bf16x2(lo.x * sc, lo.y * sc); r.y = pack_bf16x2(lo.z * sc, lo.w * sc);
+    r.z = pack_bf16x2(hi.x * sc, hi.y * sc); r.w = pack_bf16x2(hi.z * sc, hi.w * sc);
+    return r;
+}
+
+template <typename TA, typename TD>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const TA* __restrict__ a, int64_t lda, const TD* __restrict__ dy,
+                                                         int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
+                                                         float* __restrict__ dW, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * WG_ROWB];
+    char* sD = smem;                 // dy slab [64 m][96 n]
+    char* sA = smem + 64 * WG_ROWB;  // a  slab [64 m][96 k]
+    const int ntk = K / 96;
+    const int n0 = (blockIdx.x / ntk) * 96, k0 = (blockIdx.x % ntk) * 96;
+    const int64_t mbeg = (int64_t)blockIdx.y * WG_MCHUNK;
+    const int64_t mend = mbeg + WG_MCHUNK < M ? mbeg + WG_MCHUNK : M;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging: 64 rows x 12 chunks = 768 chunks per slab, 3 per thread
+    int s_row[3], s_chk[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        s_row[i] = c / 12;
+        s_chk[i] = c - s_row[i] * 12;
+    }
+    // transposed fragment reads: k-step rows 16*wave + 8h + {0..3 | 4..7}; lane supplies row (i16>>2), cols 16*(gi&1)+4*(i16&3)
+    const int i16 = lane & 15, gi = lane >> 4;
+    const int t_off = (16 * wave + 8 * h + (i16 >> 2)) * WG_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][kb][i] = 0.f;
+
+    uint4 rd[3], ra[3];
+    auto gload = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int64_t m = m0 + s_row[i];
+            if (m < mend) {
+                const float sc = row_scale ? row_scale[m / rps] : 1.0f;
+                rd[i] = stage8<TD>(dy + m * ldd + n0 + 8 * s_chk[i], sc);
+                ra[i] = stage8<TA>(a + m * lda + k0 + 8 * s_chk[i], 1.0f);
+            } else {
+                rd[i] = make_uint4(0, 0, 0, 0);
+                ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    gload(mbeg);
+    for (int64_t m0 = mbeg; m0 < mend; m0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<uint4*>(sD + s_row[i] * WG_ROWB + s_chk[i] * 16) = rd[i];
+            *reinterpret_cast<uint4*>(sA + s_row[i] * WG_ROWB + s_chk[i] * 16) = ra[i];
+        }
+        __syncthreads();
+        if (m0 + 64 < mend) gload(m0 + 64);
+        bf16x8 df[3], af[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sD + t_off + b * 64));
+            const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sD + t_off + b * 64 + 4 * WG_ROWB));
+            const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sA + t_off + b * 64));
+            const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sA + t_off + b * 64 + 4 * WG_ROWB));
+            df[b][0] = dlo[0]; df[b][1] = dlo[1]; df[b][2] = dlo[2]; df[b][3] = dlo[3];
+            df[b][4] = dhi[0]; df[b][5] = dhi[1]; df[b][6] = dhi[2]; df[b][7] = dhi[3];
+            af[b][0] = alo[0]; af[b][1] = alo[1]; af[b][2] = alo[2]; af[b][3] = alo[3];
+            af[b][4] = ahi[0]; af[b][5] = ahi[1]; af[b][6] = ahi[2]; af[b][7] = ahi[3];
+        }
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+                acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[nb], af[kb], acc[nb][kb], 0, 0, 0);
+    }
+    // acc[nb][kb][i]: row n = 32nb + (i&3) + 8(i>>2) + 4h, col k = 32kb + r
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + 32 * nb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                atomicAdd(dW + (int64_t)n * K + k0 + 32 * kb + r, acc[nb][kb][i]);
+            }
+}
+
+// exact fp32: 64(n) x 64(k) tile per block over an M chunk, 4x4 per thread
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy,
+                                                        int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
+                                                        float* __restrict__ dW, int64_t M, int N, int K) {
+    __shared__ float Ds[16][68];
+    __shared__ float As[16][68];
+    const int ntk = (K + 63) / 64;
+    const int n0 = (blockIdx.x / ntk) * 64, k0 = (blockIdx.x % ntk) * 64;
+    const int64_t mbeg = (int64_t)blockIdx.y * WG_MCHUNK;
+    const int64_t mend = mbeg + WG_MCHUNK < M ? mbeg + WG_MCHUNK : M;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int lm = tid >> 4, lc = (tid & 15) * 4;   // loader: row lm (0..15), 4 columns at lc
+    float acc[4][4] = {};
+    for (int64_t m0 = mbeg; m0 < mend; m0 += 16) {
+        const int64_t m = m0 + lm;
+        float4 dv = make_float4(0.f, 0.f, 0.f, 0.f), av = dv;
+        if (m < mend) {
+            const float sc = row_scale ? row_scale[m / rps] : 1.0f;
+            if (n0 + lc + 3 < N) { dv = load4(dy + m * ldd + n0 + lc); }
+            else { float t[4] = {0, 0, 0, 0}; for (int e = 0; e < 4; ++e) if (n0 + lc + e < N) t[e] = dy[m * ldd + n0 + lc + e]; dv = make_float4(t[0], t[1], t[2], t[3]); }
+            dv.x *= sc; dv.y *= sc; dv.z *= sc; dv.w *= sc;
+            if (k0 + lc + 3 < K) { av = load4(a + m * lda + k0 + lc); }
+            else { float t[4] = {0, 0, 0, 0}; for (int e = 0; e < 4; ++e) if (k0 + lc + e < K) t[e] = a[m * lda + k0 + lc + e]; av = make_float4(t[0], t[1], t[2], t[3]); }
+        }
+        __syncthreads();
+        *reinterpret_cast<float4*>(&Ds[lm][lc]) = dv;
+        *reinterpret_cast<float4*>(&As[lm][lc]) = av;
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            const float4 d4 = *reinterpret_cast<const float4*>(&Ds[mm][ty * 4]);
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[mm][tx * 4]);
+            const float dr[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float ar[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dr[i], ar[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + ty * 4 + i, k = k0 + tx * 4 + j;
+            if (n < N && k < K) atomicAdd(dW + (int64_t)n * K + k, acc[i][j]);
+        }
+}
+
+// dW must be zeroed (or hold the value to accumulate onto) by the caller.
+extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                                 const float* row_scale, int64_t rows_per_scale, float* dW, int64_t M, int N, int K,
+                                 int act_dtype, void* stream) {
+    if (!a || !dy || !dW || M <= 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
+    if (row_scale && rows_per_scale <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int64_t mchunks = (M + WG_MCHUNK - 1) / WG_MCHUNK;
+    if (mchunks > 65535) return MVIT_EINVAL;
+    if (act_dtype == MVIT_F32) {
+        if (a_dtype != MVIT_F32 || dy_dtype != MVIT_F32) return MVIT_EDTYPE;
+        if ((lda & 3) || (ldd & 3)) return MVIT_EUNSUPPORTED;
+        dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)mchunks);
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
+                           rows_per_scale, dW, M, N, K);
+        MVIT_LAUNCH_CHECK();
+        return MVIT_OK;
+    }
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return MVIT_EUNSUPPORTED;
+    dim3 grid((N / 96) * (K / 96), (unsigned)mchunks);
+#define WG(TA, TD) \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(256), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, M, N, K)
+    if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16) WG(bf16_t, bf16_t);
+    else if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_F32) WG(bf16_t, float);
+    else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_F32) WG(float, float);
+    else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_BF16) WG(float, bf16_t);
+    else return MVIT_EDTYPE;
+#undef WG
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}

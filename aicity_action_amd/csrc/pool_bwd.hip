@@ -1,0 +1,311 @@
+// Backward of the pooling conv + LayerNorm (attention_pool, conv variant).  v1: straightforward gather kernels
+// (HBM/L2-bound, fp32 accumulate), three launches:
+//   1. pool_ln_bwd_kernel : recompute conv + LN statistics per output token, LN backward -> d_conv (act-typed),
+//                           partial sums of d_gamma / d_beta (deterministic two-stage reduction)
+//   2. pool_dgrad_kernel  : transposed depthwise conv of d_conv, written into the q/k/v slice of the fused d_qkv buffer
+//   3. pool_wgrad_kernel  : dw[c][tap] += sum_tokens d_conv[tok][c] * in[pos(tok,tap)][c]   (fp32 atomics, 27x96 outputs)
+#include "common.h"
+
+#define PB_MAXBLK 1024
+
+template <typename TA>
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
+                                                          const float* __restrict__ w, const float* __restrict__ gamma,
+                                                          const TA* __restrict__ dout, TA* __restrict__ dconv,
+                                                          float* __restrict__ part, int B, int heads, int T, int H, int W,
+                                                          int Ho, int Wo, int s, float eps) {
+    constexpr int CW = 16 / sizeof(TA);
+    constexpr int NCH = 24 / CW;
+    __shared__ __attribute__((aligned(16))) float wsm[27 * 96];
+    __shared__ float red[64][4];   // reused for the final reduction in chunks
+    for (int i = threadIdx.x; i < 27 * 96; i += 256) {
+        const int tap = i / 96, c = i - tap * 96;
+        wsm[i] = w[c * 27 + tap];
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 3;
+    float g[24], ag[24], ab[24];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) g[i * CW + e] = gamma[CW * (j + 4 * i) + e];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+    const int64_t Lout = (int64_t)T * Ho * Wo;
+    const int64_t total = (int64_t)B * heads * Lout;
+    const int64_t Nin = (int64_t)T * H * W;
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < total; it0 += (int64_t)gridDim.x * 64) {
+        const int64_t it = it0 + (threadIdx.x >> 2);
+        const bool ok = it < total;
+        const int64_t itc = ok ? it : total - 1;
+        int64_t rem = itc;
+        const int xo = (int)(rem % Wo); rem /= Wo;
+        const int yo = (int)(rem % Ho); rem /= Ho;
+        const int to = (int)(rem % T); rem /= T;
+        const int gh = (int)(rem % heads);
+        const int b = (int)(rem / heads);
+        const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + gh * 96;
+        float acc[24];
+#pragma unroll
+        for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int ti = to + dt - 1;
+            if (ti < 0 || ti >= T) continue;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yi = yo * s + dy - 1;
+                if (yi < 0 || yi >= H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xi = xo * s + dx - 1;
+                    if (xi < 0 || xi >= W) continue;
+                    const TA* p = base + (((int64_t)ti * H + yi) * W + xi) * ld;
+                    const float* wt = wsm + ((dt * 3 + dy) * 3 + dx) * 96;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const int c0 = CW * (j + 4 * i);
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) {
+                            const float4 v = load4(p + c0 + e);
+                            const float4 ww = *reinterpret_cast<const float4*>(wt + c0 + e);
+                            acc[i * CW + e] = fmaf(v.x, ww.x, acc[i * CW + e]);
+                            acc[i * CW + e + 1] = fmaf(v.y, ww.y, acc[i * CW + e + 1]);
+                            acc[i * CW + e + 2] = fmaf(v.z, ww.z, acc[i * CW + e + 2]);
+                            acc[i * CW + e + 3] = fmaf(v.w, ww.w, acc[i * CW + e + 3]);
+                        }
+                    }
+                }
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 24; ++e) sum += acc[e];
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float mean = sum * (1.0f / 96.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 24; ++e) { acc[e] -= mean; sq += acc[e] * acc[e]; }
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 96.0f) + eps);
+        float dyv[24];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < CW; e += 4) {
+                float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) d4 = load4(dout + it * 96 + CW * (j + 4 * i) + e);
+                dyv[i * CW + e] = d4.x; dyv[i * CW + e + 1] = d4.y; dyv[i * CW + e + 2] = d4.z; dyv[i * CW + e + 3] = d4.w;
+            }
+#pragma unroll
+        for (int e = 0; e < 24; ++e) {
+            acc[e] *= rstd;                  // xhat
+            ag[e] += dyv[e] * acc[e];
+            ab[e] += dyv[e];
+            dyv[e] *= g[e];                  // gamma * dy
+            c1 += dyv[e];
+            c2 += dyv[e] * acc[e];
+        }
+        c1 += __shfl_xor(c1, 1, 64); c1 += __shfl_xor(c1, 2, 64);
+        c2 += __shfl_xor(c2, 1, 64); c2 += __shfl_xor(c2, 2, 64);
+        c1 *= (1.0f / 96.0f);
+        c2 *= (1.0f / 96.0f);
+        if (ok) {
+            TA* o = dconv + it * 96;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < CW; e += 4) {
+                    const int k = i * CW + e;
+                    float4 v;
+                    v.x = rstd * (dyv[k] - c1 - acc[k] * c2);
+                    v.y = rstd * (dyv[k + 1] - c1 - acc[k + 1] * c2);
+                    v.z = rstd * (dyv[k + 2] - c1 - acc[k + 2] * c2);
+                    v.w = rstd * (dyv[k + 3] - c1 - acc[k + 3] * c2);
+                    store4(o + CW * (j + 4 * i) + e, v);
+                }
+        }
+    }
+    // block reduction of the dgamma / dbeta partials: lanes with equal j own the same 24 channels
+    auto block_reduce = [&](const float (&src)[24], int pass) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e) {
+            __syncthreads();
+            red[threadIdx.x >> 2][j] = src[e];
+            __syncthreads();
+            if (threadIdx.x < 4) {
+                float t = 0.f;
+                for (int rr = 0; rr < 64; ++rr) t += red[rr][threadIdx.x];
+                // channel of (j = threadIdx.x, element e): chunk i = e / CW, offset e % CW
+                const int c = CW * (threadIdx.x + 4 * (e / CW)) + (e % CW);
+                part[(int64_t)blockIdx.x * 192 + pass * 96 + c] = t;
+            }
+        }
+    };
+    block_reduce(ag, 0);
+    block_reduce(ab, 1);
+}
+
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int accumulate) {
+    const int j = threadIdx.x;
+    if (j >= 192) return;
+    float s = 0.f;
+    for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * 192 + j];
+    float* o = j < 96 ? dgamma + j : dbeta + (j - 96);
+    *o = accumulate ? *o + s : s;
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(const TA* __restrict__ dconv, const float* __restrict__ w,
+                                                         TA* __restrict__ dqkv, int64_t ld, int chan_off, int B, int heads,
+                                                         int T, int H, int W, int Ho, int Wo, int s) {
+    constexpr int CW = 16 / sizeof(TA);
+    constexpr int NCH = 24 / CW;
+    __shared__ __attribute__((aligned(16))) float wsm[27 * 96];
+    for (int i = threadIdx.x; i < 27 * 96; i += 256) {
+        const int tap = i / 96, c = i - tap * 96;
+        wsm[i] = w[c * 27 + tap];
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 3;
+    const int64_t Nin = (int64_t)T * H * W;
+    const int64_t total = (int64_t)B * heads * Nin;
+    const int64_t Lout = (int64_t)T * Ho * Wo;
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < total; it0 += (int64_t)gridDim.x * 64) {
+        const int64_t it = it0 + (threadIdx.x >> 2);
+        if (it >= total) continue;
+        int64_t rem = it;
+        const int x = (int)(rem % W); rem /= W;
+        const int y = (int)(rem % H); rem /= H;
+        const int t = (int)(rem % T); rem /= T;
+        const int gh = (int)(rem % heads);
+        const int b = (int)(rem / heads);
+        float acc[24];
+#pragma unroll
+        for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int to = t + 1 - dt;
+            if (to < 0 || to >= T) continue;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int ny = y + 1 - dy;
+                if (ny < 0 || ny % s) continue;
+                const int yo = ny / s;
+                if (yo >= Ho) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int nx = x + 1 - dx;
+                    if (nx < 0 || nx % s) continue;
+                    const int xo = nx / s;
+                    if (xo >= Wo) continue;
+                    const TA* p = dconv + (((int64_t)(b * heads + gh)) * Lout + ((int64_t)to * Ho + yo) * Wo + xo) * 96;
+                    const float* wt = wsm + ((dt * 3 + dy) * 3 + dx) * 96;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const int c0 = CW * (j + 4 * i);
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) {
+                            const float4 v = load4(p + c0 + e);
+                            const float4 ww = *reinterpret_cast<const float4*>(wt + c0 + e);
+                            acc[i * CW + e] = fmaf(v.x, ww.x, acc[i * CW + e]);
+                            acc[i * CW + e + 1] = fmaf(v.y, ww.y, acc[i * CW + e + 1]);
+                            acc[i * CW + e + 2] = fmaf(v.z, ww.z, acc[i * CW + e + 2]);
+                            acc[i * CW + e + 3] = fmaf(v.w, ww.w, acc[i * CW + e + 3]);
+                        }
+                    }
+                }
+            }
+        }
+        TA* o = dqkv + ((int64_t)b * Nin + ((int64_t)t * H + y) * W + x) * ld + chan_off + gh * 96;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < CW; e += 4)
+                store4(o + CW * (j + 4 * i) + e, make_float4(acc[i * CW + e], acc[i * CW + e + 1], acc[i * CW + e + 2], acc[i * CW + e + 3]));
+    }
+}
+
+#define PW_CHUNK 512
+template <typename TA>
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
+                                                         const TA* __restrict__ dconv, float* __restrict__ dw, int B,
+                                                         int heads, int T, int H, int W, int Ho, int Wo, int s) {
+    const int c = threadIdx.x % 96, half = threadIdx.x / 96;   // half 0: taps 0..13, half 1: taps 14..26
+    const int tap0 = half * 14, ntap = half ? 13 : 14;
+    const int64_t Lout = (int64_t)T * Ho * Wo;
+    const int64_t total = (int64_t)B * heads * Lout;
+    const int64_t Nin = (int64_t)T * H * W;
+    float acc[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) acc[k] = 0.f;
+    const int64_t beg = (int64_t)blockIdx.x * PW_CHUNK;
+    const int64_t end = beg + PW_CHUNK < total ? beg + PW_CHUNK : total;
+    for (int64_t it = beg; it < end; ++it) {
+        int64_t rem = it;
+        const int xo = (int)(rem % Wo); rem /= Wo;
+        const int yo = (int)(rem % Ho); rem /= Ho;
+        const int to = (int)(rem % T); rem /= T;
+        const int gh = (int)(rem % heads);
+        const int b = (int)(rem / heads);
+        const float d = ActIO<TA>::load(dconv + it * 96 + c);
+        const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + gh * 96 + c;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            if (k < ntap) {
+                const int tap = tap0 + k;
+                const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                const int ti = to + dt - 1, yi = yo * s + dy - 1, xi = xo * s + dx - 1;
+                if (ti >= 0 && ti < T && yi >= 0 && yi < H && xi >= 0 && xi < W)
+                    acc[k] = fmaf(d, ActIO<TA>::load(base + (((int64_t)ti * H + yi) * W + xi) * ld), acc[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 14; ++k)
+        if (k < ntap) atomicAdd(dw + c * 27 + tap0 + k, acc[k]);
+}
+
+extern "C" int64_t mvit_pool_bwd_workspace_bytes(void) { return (int64_t)PB_MAXBLK * 192 * sizeof(float); }
+
+// dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.
+// dw [96][27] fp32 is ACCUMULATED into (caller zeroes it once per step); dgamma/dbeta: accumulate flag.
+extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                                     const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
+                                     int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
+                                     int stride_hw, float eps, int act_dtype, void* stream) {
+    if (!qkv || !w || !gamma || !dout || !dconv || !dqkv || !dw || !dgamma || !dbeta || !workspace || B <= 0 ||
+        heads <= 0 || T <= 0 || H <= 0 || W <= 0 || stride_hw <= 0)
+        return MVIT_EINVAL;
+    if ((ld & 7) || (chan_off & 7)) return MVIT_EUNSUPPORTED;
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    hipStream_t st = as_stream(stream);
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    const int64_t tot_out = (int64_t)B * heads * T * Ho * Wo;
+    const int64_t tot_in = (int64_t)B * heads * T * H * W;
+    int64_t b1 = (tot_out + 63) / 64;
+    if (b1 > PB_MAXBLK) b1 = PB_MAXBLK;
+    int64_t b2 = (tot_in + 63) / 64;
+    if (b2 > 16384) b2 = 16384;
+    const int64_t b3 = (tot_out + PW_CHUNK - 1) / PW_CHUNK;
+    if (b3 > 0x7fffffff) return MVIT_EINVAL;
+#define RUN(TA)                                                                                                            \
+    hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w,     \
+                       gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);          \
+    MVIT_LAUNCH_CHECK();                                                                                                   \
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, (int)b1, dgamma, dbeta, accumulate_param); \
+    MVIT_LAUNCH_CHECK();                                                                                                   \
+    hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
+                       chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
+    MVIT_LAUNCH_CHECK();                                                                                                   \
+    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(192), 0, st, (const TA*)qkv, ld, chan_off,         \
+                       (const TA*)dconv, dw, B, heads, T, H, W, Ho, Wo, stride_hw);                                        \
+    MVIT_LAUNCH_CHECK();
+    if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
+#undef RUN
+    return MVIT_OK;
+}

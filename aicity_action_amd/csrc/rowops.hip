@@ -189,6 +189,24 @@ extern "C" int64_t mvit_head_workspace_bytes(int B, int N, int C) {
     return (int64_t)B * nchunks * C * (int64_t)sizeof(float);
 }
 
+// stage 1 only (training path): per-chunk sums of LN(x) over tokens -> workspace [B][nchunks][C], nchunks = ceil(N/32)
+extern "C" int mvit_head_ln_partial(const float* x, const float* gamma, const float* beta, float* workspace, int B, int N,
+                                    int C, float eps, void* stream) {
+    if (!x || !gamma || !beta || !workspace || B <= 0 || N <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const int nchunks = (N + HEAD_CHUNK - 1) / HEAD_CHUNK;
+    dim3 grid(nchunks, B);
+    switch (C) {
+        case 96: hipLaunchKernelGGL((head_ln_partial_kernel<96>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 192: hipLaunchKernelGGL((head_ln_partial_kernel<192>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 384: hipLaunchKernelGGL((head_ln_partial_kernel<384>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        case 768: hipLaunchKernelGGL((head_ln_partial_kernel<768>), grid, dim3(256), 0, st, x, gamma, beta, workspace, N, nchunks, eps); break;
+        default: return MVIT_EUNSUPPORTED;
+    }
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 extern "C" int mvit_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_head,
                              const float* b_head, float* workspace, float* logits, float* probs, int B, int N, int C,
                              int num_classes, float eps, void* stream) {

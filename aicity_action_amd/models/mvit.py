@@ -195,7 +195,8 @@ class MViT(nn.Module):
             x = x[0]                                                 # :1165-1167
         if not x.is_cuda:
             raise RuntimeError("MViT (HIP path) needs its input on a gfx950 device; there is no CPU fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
             return forward_with_grad(self, x, return_logits)
         return self._forward_hip(x, return_logits)
@@ -282,7 +283,7 @@ class MViT(nn.Module):
         del qkv
         # 4. fused attention (+ pooled-q residual), heads merged on store   attention.py:267-279
         o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
-        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), B, h, Lq, Lk,
+        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), None, B, h, Lq, Lk,
                                         96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st), "attention")
         if taps is not None:
             taps["block%d.q" % g.index] = q

@@ -1,0 +1,171 @@
+"""Optimizer / LR schedule of the train step, on multi-tensor HIP kernels.
+
+Mirrors the reference's ``construct_optimizer`` parameter grouping and AdamW hyper-parameters
+(slowfast/models/optimizer.py:26-210: 1-D tensors get weight decay 0 when SOLVER.ZERO_WD_1D_PARAM, names in
+``model.no_weight_decay()`` too), ``set_lr`` (:224-236), the cosine + linear warm-up policy
+(slowfast/utils/lr_policy.py:9-53) and ``clip_grad_norm_(params, SOLVER.CLIP_GRAD_L2NORM)``
+(tools/train_net.py:239-243).  The arithmetic is two kernels per step (global grad norm, fused AdamW) over a device
+table of chunk descriptors instead of ~350 small kernels.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _hip
+
+_CHUNK = 65536
+_DT = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i4"), ("wd", "f4")])
+
+
+def lr_func_cosine(cfg, cur_epoch):
+    s = cfg.SOLVER
+    offset = s.WARMUP_EPOCHS if s.COSINE_AFTER_WARMUP else 0.0
+    assert s.COSINE_END_LR < s.BASE_LR
+    return s.COSINE_END_LR + (s.BASE_LR - s.COSINE_END_LR) * (
+        math.cos(math.pi * (cur_epoch - offset) / (s.MAX_EPOCH - offset)) + 1.0) * 0.5
+
+
+def get_lr_at_epoch(cfg, cur_epoch):
+    if cfg.SOLVER.LR_POLICY != "cosine":
+        raise NotImplementedError("Unknown LR policy: {}".format(cfg.SOLVER.LR_POLICY))
+    lr = lr_func_cosine(cfg, cur_epoch)
+    if cur_epoch < cfg.SOLVER.WARMUP_EPOCHS:
+        lr_start = cfg.SOLVER.WARMUP_START_LR
+        lr_end = lr_func_cosine(cfg, cfg.SOLVER.WARMUP_EPOCHS)
+        alpha = (lr_end - lr_start) / cfg.SOLVER.WARMUP_EPOCHS
+        lr = cur_epoch * alpha + lr_start
+    return lr
+
+
+def param_groups(model, cfg):
+    """(decay, no_decay) lists of (name, param) following optimizer.py:56-75."""
+    mod = model.module if hasattr(model, "module") else model
+    skip = mod.no_weight_decay() if hasattr(mod, "no_weight_decay") else {}
+    decay, no_decay = [], []
+    for name, m in mod.named_modules():
+        for pname, p in m.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            full = (name + "." if name else "") + pname
+            if name in skip or full in skip:
+                no_decay.append((full, p))
+            elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.ndim == 1 or name.endswith(".bias")):
+                no_decay.append((full, p))
+            else:
+                decay.append((full, p))
+    return decay, no_decay
+
+
+class HipAdamW(object):
+    """AdamW(betas (0.9, 0.999), eps 1e-8) with fused global-norm clipping, fp32 state."""
+
+    def __init__(self, model, cfg):
+        if cfg.SOLVER.OPTIMIZING_METHOD != "adamw":
+            raise NotImplementedError("Does not support {} optimizer".format(cfg.SOLVER.OPTIMIZING_METHOD))
+        self.cfg = cfg
+        self.lr = cfg.SOLVER.BASE_LR
+        self.betas = (0.9, 0.999)
+        self.eps = 1e-8
+        self.step_count = 0
+        decay, no_decay = param_groups(model, cfg)
+        self.groups = [{"params": [p for _, p in decay], "names": [n for n, _ in decay], "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
+                       {"params": [p for _, p in no_decay], "names": [n for n, _ in no_decay], "weight_decay": 0.0}]
+        self.state = {}
+        for grp in self.groups:
+            for p in grp["params"]:
+                self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                 torch.zeros_like(p, memory_format=torch.contiguous_format))
+        self._table = None
+        self._grad_ptrs = None
+        self.last_grad_norm = None
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+
+    def zero_grad(self, set_to_none=False):
+        for grp in self.groups:
+            for p in grp["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    def _build(self):
+        rec, ptrs = [], []
+        for grp in self.groups:
+            for p in grp["params"]:
+                assert p.grad is not None and p.grad.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
+                m, v = self.state[p]
+                n = p.numel()
+                ptrs.append(p.grad.data_ptr())
+                for off in range(0, n, _CHUNK):
+                    rec.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, m.data_ptr() + 4 * off,
+                                v.data_ptr() + 4 * off, min(_CHUNK, n - off), grp["weight_decay"]))
+        dev = self.groups[0]["params"][0].device
+        assert _hip.lib().mvit_mt_chunk_bytes() == _DT.itemsize
+        self._table = torch.from_numpy(np.array(rec, dtype=_DT).view(np.uint8).copy()).to(dev)
+        self._n = len(rec)
+        self._partials = torch.empty(self._n, dtype=torch.float32, device=dev)
+        self._out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        self._grad_ptrs = ptrs
+
+    def step(self, max_norm=None):
+        """One clipped AdamW step.  max_norm None -> cfg.SOLVER.CLIP_GRAD_L2NORM (None/0 disables clipping)."""
+        cur = [p.grad.data_ptr() if p.grad is not None else 0 for grp in self.groups for p in grp["params"]]
+        if self._table is None or cur != self._grad_ptrs:
+            self._build()                                   # grads were re-allocated (e.g. set_to_none): refresh the table
+        if max_norm is None:
+            max_norm = self.cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0
+        L = _hip.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        self.step_count += 1
+        _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, float(max_norm), _hip.ptr(self._partials),
+                                    _hip.ptr(self._out2), st), "grad_norm")
+        _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
+                                     self.eps, self.step_count, st), "adamw")
+        self.last_grad_norm = self._out2      # device tensor [norm, coef]; no host sync here
+        return self._out2
+
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.lr,
+                "state": {n: (self.state[p][0], self.state[p][1]) for grp in self.groups for n, p in zip(grp["names"], grp["params"])}}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.lr = sd["lr"]
+        for grp in self.groups:
+            for n, p in zip(grp["names"], grp["params"]):
+                m, v = sd["state"][n]
+                self.state[p][0].copy_(m)
+                self.state[p][1].copy_(v)
+
+
+def construct_optimizer(model, cfg):
+    return HipAdamW(model, cfg)
+
+
+def soft_target_cross_entropy(logits, labels):
+    """SoftTargetCrossEntropy(reduction='mean') (slowfast/models/losses.py:133-142) with a fused HIP fwd+bwd kernel."""
+    return _SoftCE.apply(logits, labels)
+
+
+class _SoftCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        L = _hip.lib()
+        logits = logits.contiguous().float()
+        labels = labels.contiguous().float()
+        B, C = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        _hip.check(L.mvit_soft_ce(_hip.ptr(logits), _hip.ptr(labels), _hip.ptr(loss), _hip.ptr(dl), B, C, 1.0,
+                                  torch.cuda.current_stream().cuda_stream), "soft_ce")
+        ctx.save_for_backward(dl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None

@@ -111,7 +111,7 @@ def main():
             o = torch.empty(args.batch, gm.lq, gm.heads * 96, device=dev, dtype=adt)
 
             def run():
-                _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), args.batch, gm.heads,
+                _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), None, args.batch, gm.heads,
                                                 gm.lq, gm.lk, 96 ** -0.5, 1, act, st))
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -79,8 +79,9 @@ int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float
 
 /* out[b][lq][g*96+d] = softmax_k(q.k^T * scale) . v (+ q if add_q)  -- fused, scores never stored.
  * Replaces bmm/softmax/bmm + residual at slowfast/models/attention.py:267-279.
- * q [B][heads][Lq][96], k,v [B][heads][Lk][96], out [B][Lq][heads*96], all act-typed. */
-int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int heads,
+ * q [B][heads][Lq][96], k,v [B][heads][Lk][96], out [B][Lq][heads*96], all act-typed.
+ * lse: NULL, or fp32 [B][heads][Lq] receiving log2(sum_k exp(score)) (saved for the backward pass). */
+int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
 
 /* Skip-path MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) on the token grid (slowfast/models/attention.py:
@@ -102,6 +103,86 @@ int64_t mvit_head_workspace_bytes(int B, int N, int C);
 int mvit_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_head,
                   const float* b_head, float* workspace, float* logits, float* probs, int B, int N,
                   int C, int num_classes, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training path (backward of every operator above + the optimizer step).  The reference gets these from
+ * torch.autograd (2128 backward dispatches per step); here each is one entry point.
+ * Gradients of act-typed activations are act-typed; gradients of the fp32 residual stream and of all
+ * parameters are fp32.  "accumulate" parameters select (+=) vs (=).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* LayerNorm backward (native_layer_norm_backward): statistics are recomputed from x.
+ * dy: dy_dtype-typed [rows][C]; or, when rows_per_dy > 1, fp32 [rows/rows_per_dy][C] broadcast over
+ * rows_per_dy consecutive rows and multiplied by dy_scale (backward of the token mean in the head,
+ * slowfast/models/video_model_builder.py:1310).  workspace >= mvit_layernorm_bwd_workspace_bytes(C). */
+int64_t mvit_layernorm_bwd_workspace_bytes(int C);
+int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+                       float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
+                       int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream);
+
+/* erf-GELU as separate elementwise passes (training keeps the pre-activation; slowfast/models/common.py:28). */
+int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
+int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
+
+/* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight).  dy rows may carry the per-sample
+ * drop-path factor row_scale[m / rows_per_scale].  dW is accumulated into (zero it once per step). */
+int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                      const float* row_scale, int64_t rows_per_scale, float* dW, int64_t M, int N, int K,
+                      int act_dtype, void* stream);
+
+/* out[n] (+)= sum_m row_scale[m/rps] * a[m][n]  (bias gradients).  workspace >= mvit_colsum_workspace_bytes(N). */
+int64_t mvit_colsum_workspace_bytes(int N);
+int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_scale, int64_t rows_per_scale,
+                float* out, int accumulate, float* workspace, void* stream);
+
+/* Backward of mvit_attention_fwd (recompute from LSE; deterministic, no atomics).
+ * out / dout: [B][Lq][heads*96]; dq [B][heads][Lq][96]; dk, dv [B][heads][Lk][96]; all act-typed.
+ * workspace >= mvit_attention_bwd_workspace_bytes(B, heads, Lq). */
+int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq);
+int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
+                       const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
+                       int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
+
+/* Backward of mvit_pool_conv_ln_fwd: dout [B][heads][T*Ho*Wo][96] -> the (which) slice of dqkv [B][T*H*W][ld]
+ * (fully overwritten), dw [96][27] (accumulated), dgamma/dbeta.  dconv: scratch shaped like dout.
+ * workspace >= mvit_pool_bwd_workspace_bytes(). */
+int64_t mvit_pool_bwd_workspace_bytes(void);
+int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                          const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
+                          int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
+                          int stride_hw, float eps, int act_dtype, void* stream);
+
+/* Backward of mvit_maxpool_skip_fwd: gradient goes to the first maximum of each window (ATen semantics). */
+int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
+
+/* Stem backward: dW [96][3][3][7][7], dpos_spatial, dpos_temporal accumulated from dx [B][N][96] (the input clip
+ * needs no gradient; the bias gradient is mvit_colsum). */
+int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
+                  int T, int S, void* stream);
+
+/* Head, training variant.  mvit_head_ln_partial = stage 1 of mvit_head_fwd (workspace [B][ceil(N/32)][C]);
+ * mvit_head_project_train: z = mean * mask (dropout mask holding 0 or 1/(1-p), or NULL), logits = z W^T + b;
+ * mvit_head_bwd: dW, db, dz = mask * (dlogits W); the final-LN backward is mvit_layernorm_bwd(broadcast). */
+int mvit_head_ln_partial(const float* x, const float* gamma, const float* beta, float* workspace, int B, int N, int C,
+                         float eps, void* stream);
+int mvit_head_project_train(const float* partials, const float* w_head, const float* b_head, const float* mask,
+                            float* z_out, float* logits, int B, int N, int nchunks, int C, int num_classes,
+                            void* stream);
+int mvit_head_bwd(const float* dlogits, const float* z, const float* w_head, const float* mask, float* dW, float* db,
+                  float* dz, int B, int C, int num_classes, int accumulate, void* stream);
+
+/* SoftTargetCrossEntropy, reduction mean (slowfast/models/losses.py:133-142): loss scalar + dlogits*grad_scale. */
+int mvit_soft_ce(const float* logits, const float* labels, float* loss, float* dlogits, int B, int num_classes,
+                 float grad_scale, void* stream);
+
+/* Multi-tensor optimizer step over a device table of chunk descriptors {float* p,g,m,v; int n; float wd} (size
+ * mvit_mt_chunk_bytes()).  mvit_grad_norm: out2[0] = global L2 norm, out2[1] = min(1, max_norm/(norm+1e-6))
+ * (torch clip_grad_norm_, tools/train_net.py:239-243); mvit_adamw_step: torch.optim.AdamW semantics with the
+ * gradients scaled by norm_coef[1] (slowfast/models/optimizer.py:200-206). */
+int mvit_mt_chunk_bytes(void);
+int mvit_grad_norm(const void* chunk_table, int nchunks, float max_norm, float* partials, float* out2, void* stream);
+int mvit_adamw_step(const void* chunk_table, int nchunks, const float* norm_coef, float lr, float beta1, float beta2,
+                    float eps, int step, void* stream);
 
 /* fp32 -> bf16 (round to nearest even) conversion of parameters, n elements. */
 int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

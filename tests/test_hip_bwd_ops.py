@@ -1,0 +1,306 @@
+"""GPU: every backward / training-step C-ABI operator against torch autograd of the oracle's op on the CPU."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mvit_oracle as O
+from aicity_action_amd import _hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _act(t, act):
+    return t.to(torch.bfloat16) if act == _hip.BF16 else t.float()
+
+
+def _close(got, ref, tol):
+    got = got.float().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "max err %.3e > %.3e (scale %.3f)" % (err, tol * scale, scale)
+
+
+@pytest.mark.parametrize("dyt", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("C,rows", [(96, 1000), (192, 37), (384, 392), (768, 65)])
+def test_layernorm_bwd(hip_lib, dyt, C, rows):
+    x = (_rnd(rows, C, seed=1) * 2 + 0.5).requires_grad_(True)
+    g = (1 + 0.1 * _rnd(C, seed=2)).requires_grad_(True)
+    b = (0.1 * _rnd(C, seed=3)).requires_grad_(True)
+    dy = _act(_rnd(rows, C, seed=4), dyt)
+    F.layer_norm(x, (C,), g, b, 1e-6).backward(dy.float())
+    base = _rnd(rows, C, seed=5)
+    dx = base.clone().to(DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
+    xd, gd, dyd = x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV)
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dyd), dyt, 1, 1.0, _hip.ptr(dx), 1, _hip.ptr(dg),
+                                          _hip.ptr(db), 0, _hip.ptr(ws), rows, C, 1e-6, _st()))
+    _close(dx, x.grad + base, 2e-5)
+    _close(dg, g.grad, 2e-5)
+    _close(db, b.grad, 2e-5)
+
+
+def test_layernorm_bwd_broadcast_mode(hip_lib):
+    B, N, C = 3, 50, 384
+    x = (_rnd(B * N, C, seed=6) + 0.2).requires_grad_(True)
+    g = (1 + 0.1 * _rnd(C, seed=7)).requires_grad_(True)
+    b = torch.zeros(C, requires_grad=True)
+    dz = _rnd(B, C, seed=8)
+    (F.layer_norm(x, (C,), g, b, 1e-6).reshape(B, N, C).mean(1) * dz).sum().backward()
+    dx = torch.empty(B * N, C, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
+    xd, gd, dzd = x.detach().to(DEV), g.detach().to(DEV), dz.to(DEV)
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dzd), _hip.F32, N, 1.0 / N, _hip.ptr(dx), 0,
+                                          _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws), B * N, C, 1e-6, _st()))
+    _close(dx, x.grad, 2e-5)
+    _close(dg, g.grad, 2e-5)
+    _close(db, b.grad, 2e-5)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+def test_gelu_fwd_bwd(hip_lib, act):
+    n = 4096 * 3
+    x = _act(_rnd(n, seed=9) * 2, act)
+    dy = _act(_rnd(n, seed=10), act)
+    xr = x.float().requires_grad_(True)
+    yr = F.gelu(xr)
+    yr.backward(dy.float())
+    y = torch.empty_like(x, device=DEV)
+    dx = torch.empty_like(x, device=DEV)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    _hip.check(hip_lib.mvit_gelu_fwd(_hip.ptr(xd), _hip.ptr(y), n, act, _st()))
+    _hip.check(hip_lib.mvit_gelu_bwd(_hip.ptr(xd), _hip.ptr(dyd), _hip.ptr(dx), n, act, _st()))
+    tol = 1e-2 if act else 1e-6
+    _close(y, yr.detach(), tol)
+    _close(dx, xr.grad, tol)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("M,N,K,scaled", [(1000, 288, 96, False), (2500, 96, 384, True), (129, 384, 192, False),
+                                           (3000, 192, 768, True)])
+def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
+    a = _act(_rnd(M, K, seed=11), act)
+    for dy_f32 in ([True] if act == _hip.F32 else [True, False]):
+        dy = _rnd(M, N, seed=12) if dy_f32 else _rnd(M, N, seed=12).to(torch.bfloat16)
+        rps = 500
+        sc = torch.tensor([0.0, 1.5, 2.0, 1.0, 0.5, 1.25, 3.0])[: (M + rps - 1) // rps] if scaled else None
+        dys = dy.float() * (sc.repeat_interleave(rps)[:M, None] if scaled else 1.0)
+        if act == _hip.BF16:
+            dys_m = (dy.float() * (sc.repeat_interleave(rps)[:M, None] if scaled else 1.0)).to(torch.bfloat16).float()
+        else:
+            dys_m = dys
+        ref = dys_m.t() @ a.float()
+        base = _rnd(N, K, seed=13)
+        dW = base.clone().to(DEV)
+        ad, dyd = a.to(DEV), dy.to(DEV)
+        scd = sc.to(DEV) if scaled else None
+        _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(ad), act, K, _hip.ptr(dyd), _hip.F32 if dy_f32 else _hip.BF16, N,
+                                             _hip.ptr(scd), rps if scaled else 0, _hip.ptr(dW), M, N, K, act, _st()))
+        _close(dW, ref + base, 2e-3 if act else 2e-5)
+        ws = torch.empty(hip_lib.mvit_colsum_workspace_bytes(N) // 4, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        _hip.check(hip_lib.mvit_colsum(_hip.ptr(dyd), _hip.F32 if dy_f32 else _hip.BF16, M, N, _hip.ptr(scd),
+                                       rps if scaled else 0, _hip.ptr(db), 0, _hip.ptr(ws), _st()))
+        _close(db, dys.sum(0), 2e-5)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(1, 1, 128, 64, 1), (2, 2, 100, 33, 1), (1, 2, 257, 392, 0), (1, 4, 392, 1568, 1),
+                                               (2, 1, 64, 200, 1)])
+def test_attention_bwd(hip_lib, act, B, h, Lq, Lk, add_q):
+    scale = 96 ** -0.5
+    q = _act(_rnd(B, h, Lq, 96, seed=14), act)
+    k = _act(_rnd(B, h, Lk, 96, seed=15), act)
+    v = _act(_rnd(B, h, Lk, 96, seed=16), act)
+    do = _act(_rnd(B, Lq, h * 96, seed=17), act)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    p = ((qr @ kr.transpose(-2, -1)) * scale).softmax(-1)
+    o = p @ vr
+    if add_q:
+        o = o + qr
+    o = o.transpose(1, 2).reshape(B, Lq, h * 96)
+    o.backward(do.float())
+    adt = q.dtype
+    qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
+    out = torch.empty(B, Lq, h * 96, dtype=adt, device=DEV)
+    lse = torch.empty(B, h, Lq, device=DEV)
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk,
+                                          scale, add_q, act, _st()))
+    lse_ref = torch.logsumexp((qr.detach() @ kr.detach().transpose(-2, -1)) * scale, -1) * 1.4426950408889634
+    _close(lse, lse_ref, 1e-2 if act else 1e-5)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq) // 4, device=DEV)
+    _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod),
+                                          _hip.ptr(dq), _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, add_q,
+                                          act, _st()))
+    tol = 2e-2 if act else 2e-5
+    _close(dq, qr.grad, tol)
+    _close(dk, kr.grad, tol)
+    _close(dv, vr.grad, tol)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,h,T,H,W,s", [(2, 1, 2, 16, 16, 1), (1, 2, 2, 14, 14, 2), (2, 2, 3, 7, 7, 2), (1, 1, 2, 14, 14, 4),
+                                         (1, 2, 2, 5, 9, 1)])
+def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
+    C = 96 * h
+    N = T * H * W
+    qkv = _act(_rnd(B, N, 3 * C, seed=18), act)
+    w = _rnd(96, 1, 3, 3, 3, seed=19, scale=0.3).requires_grad_(True)
+    g = (1 + 0.1 * _rnd(96, seed=20)).requires_grad_(True)
+    b = (0.1 * _rnd(96, seed=21)).requires_grad_(True)
+    which = 1
+    qkvr = qkv.float().requires_grad_(True)
+    x = qkvr[:, :, which * C:(which + 1) * C].reshape(B, N, h, 96).permute(0, 2, 1, 3)
+    out, thw = O._pool_conv_ln(x, (T, H, W), w, (1, s, s), g, b)
+    Lo = thw[0] * thw[1] * thw[2]
+    dout = _act(_rnd(B, h, Lo, 96, seed=22), act)
+    out.backward(dout.float())
+    adt = qkv.dtype
+    dqkv = torch.zeros(B, N, 3 * C, dtype=adt, device=DEV)
+    dconv = torch.empty(B, h, Lo, 96, dtype=adt, device=DEV)
+    dw = torch.zeros(96, 27, device=DEV)
+    dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+    ws = torch.empty(hip_lib.mvit_pool_bwd_workspace_bytes() // 4, device=DEV)
+    qd, wd, gd, dod = qkv.to(DEV), w.detach().to(DEV), g.detach().to(DEV), dout.to(DEV)
+    _hip.check(hip_lib.mvit_pool_conv_ln_bwd(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(dod),
+                                             _hip.ptr(dconv), _hip.ptr(dqkv), _hip.ptr(dw), _hip.ptr(dg), _hip.ptr(db), 0,
+                                             _hip.ptr(ws), B, h, T, H, W, s, 1e-5, act, _st()))
+    tol = 2e-2 if act else 3e-5
+    _close(dqkv[:, :, which * C:(which + 1) * C], qkvr.grad[:, :, which * C:(which + 1) * C], tol)
+    assert dqkv[:, :, :C].abs().max().item() == 0            # other slices untouched
+    _close(dw, w.grad.reshape(96, 27), tol)
+    _close(dg, g.grad, tol)
+    _close(db, b.grad, tol)
+
+
+@pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 1, 5, 9, 96)])
+def test_maxpool_skip_bwd(hip_lib, B, T, H, W, C):
+    x = _rnd(B, T * H * W, C, seed=23).requires_grad_(True)
+    t = x.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+    y = F.max_pool3d(t, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    Lo = y.shape[2] * y.shape[3] * y.shape[4]
+    dy = _rnd(B, Lo, C, seed=24)
+    y.reshape(B, C, Lo).transpose(1, 2).backward(dy)
+    dx = torch.empty(B, T * H * W, C, device=DEV)
+    xd, dyd = x.detach().to(DEV), dy.to(DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_bwd(_hip.ptr(xd), _hip.ptr(dyd), _hip.ptr(dx), B, T, H, W, C, _st()))
+    _close(dx, x.grad, 1e-6)
+
+
+@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56)])
+def test_stem_bwd(hip_lib, B, T, S):
+    clip = _rnd(B, 3, T, S, S, seed=25)
+    w = _rnd(96, 3, 3, 7, 7, seed=26, scale=0.05).requires_grad_(True)
+    To, So = T // 2, S // 4
+    ps = _rnd(1, So * So, 96, seed=27, scale=0.02).requires_grad_(True)
+    pt = _rnd(1, To, 96, seed=28, scale=0.02).requires_grad_(True)
+    x = F.conv3d(clip, w, None, stride=(2, 4, 4), padding=(1, 3, 3)).flatten(2).transpose(1, 2)
+    x = x + (ps.repeat(1, To, 1) + torch.repeat_interleave(pt, So * So, dim=1))
+    dx = _rnd(B, To * So * So, 96, seed=29)
+    x.backward(dx)
+    dW = torch.zeros(96, 441, device=DEV)
+    dps, dpt = torch.zeros(So * So, 96, device=DEV), torch.zeros(To, 96, device=DEV)
+    cd, dxd = clip.to(DEV), dx.to(DEV)
+    _hip.check(hip_lib.mvit_stem_bwd(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, _st()))
+    _close(dW, w.grad.reshape(96, 441), 3e-5)
+    _close(dps, ps.grad[0], 2e-5)
+    _close(dpt, pt.grad[0], 2e-5)
+
+
+def test_head_train_and_bwd(hip_lib):
+    B, N, C = 3, 50, 384
+    x = (_rnd(B, N, C, seed=30) + 0.3).requires_grad_(True)
+    g = (1 + 0.1 * _rnd(C, seed=31)).requires_grad_(True)
+    b = (0.1 * _rnd(C, seed=32)).requires_grad_(True)
+    w = _rnd(18, C, seed=33, scale=0.05).requires_grad_(True)
+    hb = _rnd(18, seed=34, scale=0.1).requires_grad_(True)
+    mask = (torch.rand(B, C, generator=torch.Generator().manual_seed(35)) > 0.5).float() * 2.0
+    labels = torch.zeros(B, 18)
+    labels[0, 3], labels[1, 5], labels[2, 7], labels[2, 8] = 1.0, 1.0, 0.7, 0.3
+    z = F.layer_norm(x, (C,), g, b, 1e-6).mean(1) * mask
+    logits = F.linear(z, w, hb)
+    loss = O.soft_target_cross_entropy(logits, labels)
+    loss.backward()
+    nch = (N + 31) // 32
+    ws = torch.empty(B * nch * C, device=DEV)
+    xd, gd, bd, wd, hbd, md, ld = (t.detach().to(DEV) for t in (x, g, b, w, hb, mask, labels))
+    zo = torch.empty(B, C, device=DEV)
+    lg = torch.empty(B, 18, device=DEV)
+    _hip.check(hip_lib.mvit_head_ln_partial(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(ws), B, N, C, 1e-6, _st()))
+    _hip.check(hip_lib.mvit_head_project_train(_hip.ptr(ws), _hip.ptr(wd), _hip.ptr(hbd), _hip.ptr(md), _hip.ptr(zo), _hip.ptr(lg),
+                                               B, N, nch, C, 18, _st()))
+    _close(lg, logits.detach(), 1e-5)
+    lossd = torch.empty(1, device=DEV)
+    dl = torch.empty(B, 18, device=DEV)
+    _hip.check(hip_lib.mvit_soft_ce(_hip.ptr(lg), _hip.ptr(ld), _hip.ptr(lossd), _hip.ptr(dl), B, 18, 1.0, _st()))
+    assert abs(lossd.item() - loss.item()) < 1e-5
+    dW, dbh, dz = torch.empty(18, C, device=DEV), torch.empty(18, device=DEV), torch.empty(B, C, device=DEV)
+    _hip.check(hip_lib.mvit_head_bwd(_hip.ptr(dl), _hip.ptr(zo), _hip.ptr(wd), _hip.ptr(md), _hip.ptr(dW), _hip.ptr(dbh),
+                                     _hip.ptr(dz), B, C, 18, 0, _st()))
+    _close(dW, w.grad, 1e-5)
+    _close(dbh, hb.grad, 1e-5)
+    dx = torch.empty(B * N, C, device=DEV)
+    dg, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ws2 = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dz), _hip.F32, N, 1.0 / N, _hip.ptr(dx), 0,
+                                          _hip.ptr(dg), _hip.ptr(dbeta), 0, _hip.ptr(ws2), B * N, C, 1e-6, _st()))
+    _close(dx.view(B, N, C), x.grad, 1e-5)
+    _close(dg, g.grad, 1e-5)
+    _close(dbeta, b.grad, 1e-5)
+
+
+def test_grad_norm_and_adamw_match_torch(hip_lib):
+    torch.manual_seed(0)
+    shapes = [(96, 3, 3, 7, 7), (288, 96), (288,), (96,), (5000,), (384, 96)]
+    wds = [1e-4, 1e-4, 0.0, 0.0, 0.0, 1e-4]
+    ps = [torch.randn(s) for s in shapes]
+    gs = [torch.randn(s) * 0.5 for s in shapes]
+    ref_p = [p.clone().requires_grad_(True) for p in ps]
+    for p, g in zip(ref_p, gs):
+        p.grad = g.clone()
+    opt = torch.optim.AdamW([{"params": [p for p, w in zip(ref_p, wds) if w > 0], "weight_decay": 1e-4},
+                             {"params": [p for p, w in zip(ref_p, wds) if w == 0], "weight_decay": 0.0}], lr=1e-3,
+                            betas=(0.9, 0.999), eps=1e-8)
+    norm = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+    dp = [p.clone().to(DEV) for p in ps]
+    dg = [g.clone().to(DEV) for g in gs]
+    dm = [torch.zeros_like(p) for p in dp]
+    dv = [torch.zeros_like(p) for p in dp]
+    CH = 2048
+    rec = []
+    for p, g, m, v, wd in zip(dp, dg, dm, dv, wds):
+        n = p.numel()
+        for off in range(0, n, CH):
+            rec.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off,
+                        min(CH, n - off), wd))
+    assert hip_lib.mvit_mt_chunk_bytes() == 40
+    dt = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i4"), ("wd", "f4")])
+    table = torch.from_numpy(np.array(rec, dtype=dt).view(np.uint8).copy()).to(DEV)
+    partials = torch.empty(len(rec), device=DEV)
+    out2 = torch.empty(2, device=DEV)
+    for step in (1, 2):
+        if step == 2:
+            for p, g in zip(ref_p, gs):
+                p.grad = g.clone()
+            norm = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        opt.step()
+        _hip.check(hip_lib.mvit_grad_norm(_hip.ptr(table), len(rec), 1.0, _hip.ptr(partials), _hip.ptr(out2), _st()))
+        assert abs(out2[0].item() - norm.item()) <= 1e-4 * norm.item()
+        _hip.check(hip_lib.mvit_adamw_step(_hip.ptr(table), len(rec), _hip.ptr(out2), 1e-3, 0.9, 0.999, 1e-8, step, _st()))
+        for p, r in zip(dp, ref_p):
+            _close(p, r.detach(), 2e-6)

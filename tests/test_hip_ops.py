@@ -140,7 +140,7 @@ def test_attention(hip_lib, act, B, h, Lq, Lk, add_q):
     ref = ref.transpose(1, 2).reshape(B, Lq, h * 96)
     out = torch.empty(B, Lq, h * 96, dtype=q.dtype, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), B, h, Lq, Lk, scale,
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), None, B, h, Lq, Lk, scale,
                                           add_q, act, _st()))
     _close(out, ref, _tol(act, fp32=2e-5, bf16=1e-2))
 
@@ -158,7 +158,7 @@ def test_attention_bf16_online_softmax_rescale_is_exercised(hip_lib):
     ref = (((q.float() @ k.float().transpose(-2, -1)) * scale).softmax(-1) @ v.float()).transpose(1, 2).reshape(B, Lq, 96)
     out = torch.empty(B, Lq, 96, dtype=torch.bfloat16, device=DEV)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), B, h, Lq, Lk, scale, 0,
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), None, B, h, Lq, Lk, scale, 0,
                                           _hip.BF16, _st()))
     _close(out, ref, 1e-2)
 

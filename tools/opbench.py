@@ -62,7 +62,7 @@ def main():
         o = torch.empty(B, Lq, h * 96, device=dev, dtype=torch.bfloat16)
 
         def fn():
-            _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), B, h, Lq, Lk, 96 ** -0.5, 1,
+            _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), None, B, h, Lq, Lk, 96 ** -0.5, 1,
                                             _hip.BF16, st))
         ms = timeit(fn, reps)
         print("attn B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s" % (B, h, Lq, Lk, ms * 1e3, 4.0 * B * h * Lq * Lk * 96 / ms / 1e9))
