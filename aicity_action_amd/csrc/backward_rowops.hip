@@ -99,19 +99,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out[j] (+)= sum_b part[b][j]
+// out[j] (+)= sum_b part[b][j]   -- block = 64 columns x 4 part-slices, LDS combine
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
                                                               float* __restrict__ out_a, float* __restrict__ out_b,
                                                               int split, int accumulate) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= width) return;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + col;
     float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * width + j];
-    float* o = (j < split) ? out_a + j : out_b + (j - split);
-    *o = accumulate ? *o + s : s;
+    if (j < width)
+        for (int b = sl; b < nparts; b += 4) s += part[(int64_t)b * width + j];
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && j < width) {
+        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        float* o = (j < split) ? out_a + j : out_b + (j - split);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
-#define LN_BWD_MAXBLK 1024
+#define LN_BWD_MAXBLK 256
 extern "C" int64_t mvit_layernorm_bwd_workspace_bytes(int C) { return (int64_t)LN_BWD_MAXBLK * 2 * C * sizeof(float); }
 
 template <int C, typename TDY>
@@ -123,7 +130,7 @@ static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int
     hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
                        dx, acc, ws, rows, eps);
     MVIT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, ws, (int)blocks, 2 * C, dgamma,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, ws, (int)blocks, 2 * C, dgamma,
                        dbeta, C, acc_param);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
@@ -278,21 +285,40 @@ extern "C" int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx,
 // ----------------------------------------------------------------------------------------------
 // Column sums: out[n] (+)= scale-weighted sum over rows of a[M][N]  (bias gradients; two-stage).
 // ----------------------------------------------------------------------------------------------
-#define CS_MAXBLK 512
+#define CS_MAXBLK 256
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t M, int N,
                                                              const float* __restrict__ row_scale, int64_t rps,
                                                              float* __restrict__ part) {
-    // thread -> 4 consecutive columns; block strides over rows
+    // 2-D mapping: tpr = min(N/4, 256) threads per row (4 columns each), 256/tpr rows per pass; LDS combine of the row slots
+    extern __shared__ float red[];   // [rows_per_pass][N]  (only when rows_per_pass > 1)
     const int n4 = N / 4;
-    for (int c = threadIdx.x; c < n4; c += 256) {
+    const int tpr = n4 < 256 ? n4 : 256;
+    const int rpp = 256 / tpr;
+    const int rslot = threadIdx.x / tpr, c0 = threadIdx.x % tpr;
+    const bool on = rslot < rpp;
+    for (int c = c0; c < n4; c += tpr) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t m = blockIdx.x; m < M; m += gridDim.x) {
-            const float4 v = load4(a + m * N + 4 * c);
-            const float sc = row_scale ? row_scale[m / rps] : 1.f;
-            s.x += sc * v.x; s.y += sc * v.y; s.z += sc * v.z; s.w += sc * v.w;
+        if (on)
+            for (int64_t m = (int64_t)blockIdx.x * rpp + rslot; m < M; m += (int64_t)gridDim.x * rpp) {
+                const float4 v = load4(a + m * N + 4 * c);
+                const float sc = row_scale ? row_scale[m / rps] : 1.f;
+                s.x += sc * v.x; s.y += sc * v.y; s.z += sc * v.z; s.w += sc * v.w;
+            }
+        if (rpp == 1) {
+            if (on) *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * N + 4 * c) = s;
+        } else {
+            if (on) *reinterpret_cast<float4*>(red + rslot * N + 4 * c) = s;
+            __syncthreads();
+            if (rslot == 0) {
+                for (int r = 1; r < rpp; ++r) {
+                    const float4 t = *reinterpret_cast<const float4*>(red + r * N + 4 * c);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * N + 4 * c) = s;
+            }
+            __syncthreads();
         }
-        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * N + 4 * c) = s;
     }
 }
 
@@ -303,14 +329,17 @@ extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const f
     if (!a || !out || !workspace || M <= 0 || N <= 0 || (N & 3)) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
     const int blocks = (int)(M < CS_MAXBLK ? M : CS_MAXBLK);
+    const int n4 = N / 4, tpr = n4 < 256 ? n4 : 256, rpp = 256 / tpr;
+    const size_t lds = rpp > 1 ? (size_t)rpp * N * sizeof(float) : 0;
+    if (lds > 60000) return MVIT_EUNSUPPORTED;
     if (a_dtype == MVIT_F32)
-        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)a, M, N, row_scale, rows_per_scale, workspace);
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(blocks), dim3(256), lds, st, (const float*)a, M, N, row_scale, rows_per_scale, workspace);
     else if (a_dtype == MVIT_BF16)
-        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, M, N, row_scale, rows_per_scale, workspace);
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(blocks), dim3(256), lds, st, (const bf16_t*)a, M, N, row_scale, rows_per_scale, workspace);
     else
         return MVIT_EDTYPE;
     MVIT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, blocks, N, out, out, N, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, workspace, blocks, N, out, out, N, accumulate);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }

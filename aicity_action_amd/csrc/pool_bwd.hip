@@ -6,7 +6,8 @@
 //   3. pool_wgrad_kernel  : dw[c][tap] += sum_tokens d_conv[tok][c] * in[pos(tok,tap)][c]   (fp32 atomics, 27x96 outputs)
 #include "common.h"
 
-#define PB_MAXBLK 1024
+#define PB_MAXBLK 256
+#define PW_MAXBLK 512
 
 template <typename TA>
 __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
@@ -149,14 +150,22 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__
     block_reduce(ab, 1);
 }
 
-__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int accumulate) {
-    const int j = threadIdx.x;
-    if (j >= 192) return;
+// out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nparts, int width, float* __restrict__ out_a,
+                                                          float* __restrict__ out_b, int split, int accumulate) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + col;
     float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += part[(int64_t)b * 192 + j];
-    float* o = j < 96 ? dgamma + j : dbeta + (j - 96);
-    *o = accumulate ? *o + s : s;
+    if (j < width)
+        for (int b = sl; b < nparts; b += 4) s += part[(int64_t)b * width + j];
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && j < width) {
+        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        float* o = (j < split) ? out_a + j : out_b + (j - split);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 template <typename TA>
@@ -230,12 +239,15 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const TA* __restrict__ 
     }
 }
 
-#define PW_CHUNK 512
+// dw partials: block = 4 token lanes x 192 (channel, tap-half) threads; each thread walks every 4th token of the block's
+// contiguous token range with its 13/14 taps in registers; LDS combine of the 4 lanes; one partial row [2592] per block.
 template <typename TA>
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
-                                                         const TA* __restrict__ dconv, float* __restrict__ dw, int B,
+__global__ __launch_bounds__(768) void pool_wgrad_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
+                                                         const TA* __restrict__ dconv, float* __restrict__ part, int B,
                                                          int heads, int T, int H, int W, int Ho, int Wo, int s) {
-    const int c = threadIdx.x % 96, half = threadIdx.x / 96;   // half 0: taps 0..13, half 1: taps 14..26
+    __shared__ float red[3][2592];
+    const int tl = threadIdx.x / 192, t192 = threadIdx.x % 192;
+    const int c = t192 % 96, half = t192 / 96;   // half 0: taps 0..13, half 1: taps 14..26
     const int tap0 = half * 14, ntap = half ? 13 : 14;
     const int64_t Lout = (int64_t)T * Ho * Wo;
     const int64_t total = (int64_t)B * heads * Lout;
@@ -243,9 +255,10 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(const TA* __restrict__ 
     float acc[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) acc[k] = 0.f;
-    const int64_t beg = (int64_t)blockIdx.x * PW_CHUNK;
-    const int64_t end = beg + PW_CHUNK < total ? beg + PW_CHUNK : total;
-    for (int64_t it = beg; it < end; ++it) {
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t beg = (int64_t)blockIdx.x * per;
+    const int64_t end = beg + per < total ? beg + per : total;
+    for (int64_t it = beg + tl; it < end; it += 4) {
         int64_t rem = it;
         const int xo = (int)(rem % Wo); rem /= Wo;
         const int yo = (int)(rem % Ho); rem /= Ho;
@@ -265,12 +278,23 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(const TA* __restrict__ 
             }
         }
     }
+    if (tl > 0) {
 #pragma unroll
-    for (int k = 0; k < 14; ++k)
-        if (k < ntap) atomicAdd(dw + c * 27 + tap0 + k, acc[k]);
+        for (int k = 0; k < 14; ++k)
+            if (k < ntap) red[tl - 1][c * 27 + tap0 + k] = acc[k];
+    }
+    __syncthreads();
+    if (tl == 0) {
+#pragma unroll
+        for (int k = 0; k < 14; ++k)
+            if (k < ntap) {
+                const int o = c * 27 + tap0 + k;
+                part[(int64_t)blockIdx.x * 2592 + o] = acc[k] + red[0][o] + red[1][o] + red[2][o];
+            }
+    }
 }
 
-extern "C" int64_t mvit_pool_bwd_workspace_bytes(void) { return (int64_t)PB_MAXBLK * 192 * sizeof(float); }
+extern "C" int64_t mvit_pool_bwd_workspace_bytes(void) { return ((int64_t)PB_MAXBLK * 192 + (int64_t)PW_MAXBLK * 2592) * sizeof(float); }
 
 // dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.
 // dw [96][27] fp32 is ACCUMULATED into (caller zeroes it once per step); dgamma/dbeta: accumulate flag.
@@ -291,19 +315,22 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     if (b1 > PB_MAXBLK) b1 = PB_MAXBLK;
     int64_t b2 = (tot_in + 63) / 64;
     if (b2 > 16384) b2 = 16384;
-    const int64_t b3 = (tot_out + PW_CHUNK - 1) / PW_CHUNK;
-    if (b3 > 0x7fffffff) return MVIT_EINVAL;
+    int64_t b3 = (tot_out + 255) / 256;      // >= 256 tokens per block
+    if (b3 > PW_MAXBLK) b3 = PW_MAXBLK;
+    float* wpart = workspace + (int64_t)PB_MAXBLK * 192;
 #define RUN(TA)                                                                                                            \
     hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w,     \
                        gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);          \
     MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, (int)b1, dgamma, dbeta, accumulate_param); \
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3(3), dim3(256), 0, st, workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param); \
     MVIT_LAUNCH_CHECK();                                                                                                   \
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
     MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(192), 0, st, (const TA*)qkv, ld, chan_off,         \
-                       (const TA*)dconv, dw, B, heads, T, H, W, Ho, Wo, stride_hw);                                        \
+    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(768), 0, st, (const TA*)qkv, ld, chan_off,         \
+                       (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                     \
+    MVIT_LAUNCH_CHECK();                                                                                                   \
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, (int)b3, 2592, dw, dw, 2592, 1);              \
     MVIT_LAUNCH_CHECK();
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN

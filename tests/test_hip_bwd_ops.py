@@ -91,7 +91,8 @@ def test_gelu_fwd_bwd(hip_lib, act):
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("M,N,K,scaled", [(1000, 288, 96, False), (2500, 96, 384, True), (129, 384, 192, False),
-                                           (3000, 192, 768, True)])
+                                           (3000, 192, 768, True), (700, 576, 192, False), (300, 768, 96, False),
+                                           (300, 1152, 96, False)])
 def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
     a = _act(_rnd(M, K, seed=11), act)
     for dy_f32 in ([True] if act == _hip.F32 else [True, False]):
