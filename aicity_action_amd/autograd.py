@@ -64,12 +64,14 @@ class _Ctx(object):
         return y
 
     def wgrad(self, a, dy, N, K, row_scale=None, rps=0):
+        """(dW, db): weight gradient and the fused bias gradient (column sums of the scaled dy)."""
         dW = torch.zeros(N, K, dtype=torch.float32, device=a.device)
+        db = torch.zeros(N, dtype=torch.float32, device=a.device)
         adt = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
         ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
         _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
-                                            a.shape[0], N, K, self.act, _st()), "wgrad")
-        return dW
+                                            _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
+        return dW, db
 
     def colsum(self, dy, row_scale=None, rps=0):
         M, N = dy.shape
@@ -199,22 +201,19 @@ class _BlockFn(torch.autograd.Function):
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         d_out = d_out.contiguous().view(Mq, Cout)
         # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
-        dW2 = hx.wgrad(hid, d_out, Cout, 4 * Cout, dp2, Lq)
-        db2 = hx.colsum(d_out, dp2, Lq)
+        dW2, db2 = hx.wgrad(hid, d_out, Cout, 4 * Cout, dp2, Lq)
         d_hid = hx.linear(d_out, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=dp2, rps=Lq)
         d_pre = torch.empty_like(d_hid)
         _hip.check(L.mvit_gelu_bwd(_hip.ptr(pre), _hip.ptr(d_hid), _hip.ptr(d_pre), pre.numel(), act, _st()), "gelu_bwd")
         del d_hid
-        dW1 = hx.wgrad(vn, d_pre, 4 * Cout, Cout)
-        db1 = hx.colsum(d_pre)
+        dW1, db1 = hx.wgrad(vn, d_pre, 4 * Cout, Cout)
         d_vn = hx.linear(d_pre, hx.wt(blk.mlp.fc1.weight), None, adt)
         del d_pre
         d_y = d_out.clone()
         dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, True)
         del d_vn
         # ---- attention branch: y = r + dp1 * proj(o) ------------------------------------------------------
-        dWp = hx.wgrad(o, d_y, Cout, Cout, dp1, Lq)
-        dbp = hx.colsum(d_y, dp1, Lq)
+        dWp, dbp = hx.wgrad(o, d_y, Cout, Cout, dp1, Lq)
         d_o = hx.linear(d_y, hx.wt(at.proj.weight), None, adt, row_scale=dp1, rps=Lq)
         dq = torch.empty_like(q)
         dk = torch.empty_like(k)
@@ -239,8 +238,7 @@ class _BlockFn(torch.autograd.Function):
                                                _hip.ptr(dbt), 0, _hip.ptr(pws), B, h, T, H, W, stride, norm.eps, act, _st()),
                        "pool_bwd")
             pool_grads += [dw, dgm, dbt]
-        dWqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
-        dbqkv = hx.colsum(d_qkv)
+        dWqkv, dbqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
         d_u = hx.linear(d_qkv, hx.wt(at.qkv.weight), None, adt)
         del d_qkv
         # ---- skip path ------------------------------------------------------------------------------------
@@ -251,8 +249,7 @@ class _BlockFn(torch.autograd.Function):
             d_r = d_rf
         extra = []
         if g.expand:
-            dWm = hx.wgrad(x2, d_r, Cout, Cin)
-            dbm = hx.colsum(d_r)
+            dWm, dbm = hx.wgrad(x2, d_r, Cout, Cin)
             d_x = hx.linear(d_r, hx.wt(blk.proj_max_pool.weight), None, torch.float32)
             extra = [dWm, dbm]
         else:

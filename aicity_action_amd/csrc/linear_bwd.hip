@@ -36,43 +36,51 @@ __device__ __forceinline__ uint4 stage8<float>(const float* p, float sc) {
 }
 
 template <typename TA, typename TD>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const TA* __restrict__ a, int64_t lda, const TD* __restrict__ dy,
+__global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ a, int64_t lda, const TD* __restrict__ dy,
                                                          int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
-                                                         float* __restrict__ dW, int64_t M, int N, int K) {
+                                                         float* __restrict__ dW, float* __restrict__ db, int64_t M, int N, int K,
+                                                         int mchunk) {
+    // 3 waves; wave w owns the 32(n) x 96(k) strip n-block w of the 96x96 tile (48 accumulator registers -> 3-4
+    // workgroups per CU) and walks all four 16-row k-steps of every 64-row slab; no cross-wave reduction.
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * WG_ROWB];
     char* sD = smem;                 // dy slab [64 m][96 n]
     char* sA = smem + 64 * WG_ROWB;  // a  slab [64 m][96 k]
     const int ntk = K / 96;
     const int n0 = (blockIdx.x / ntk) * 96, k0 = (blockIdx.x % ntk) * 96;
-    const int64_t mbeg = (int64_t)blockIdx.y * WG_MCHUNK;
-    const int64_t mend = mbeg + WG_MCHUNK < M ? mbeg + WG_MCHUNK : M;
+    const int64_t mbeg = (int64_t)blockIdx.y * mchunk;
+    const int64_t mend = mbeg + mchunk < M ? mbeg + mchunk : M;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-
-    // staging: 64 rows x 12 chunks = 768 chunks per slab, 3 per thread
-    int s_row[3], s_chk[3];
+    const bool do_bias = db != nullptr && k0 == 0;   // block-uniform
+    f32x16 acc[3], bacc;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+    // staging: 64 rows x 12 chunks = 768 chunks per slab, 4 per thread
+    int s_off[4];
+    int s_row[4], s_chk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 192 * i;
         s_row[i] = c / 12;
         s_chk[i] = c - s_row[i] * 12;
+        s_off[i] = s_row[i] * WG_ROWB + s_chk[i] * 16;
     }
-    // transposed fragment reads: k-step rows 16*wave + 8h + {0..3 | 4..7}; lane supplies row (i16>>2), cols 16*(gi&1)+4*(i16&3)
+    // transposed fragment reads: rows 8h + {0..3 | 4..7} of a 16-row k-step; lane supplies row (i16>>2), cols 16*(gi&1)+4*(i16&3)
     const int i16 = lane & 15, gi = lane >> 4;
-    const int t_off = (16 * wave + 8 * h + (i16 >> 2)) * WG_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+    const int t_off = (8 * h + (i16 >> 2)) * WG_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
 
-    f32x16 acc[3][3];
-#pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-        for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][kb][i] = 0.f;
-
-    uint4 rd[3], ra[3];
+    uint4 rd[4], ra[4];
     auto gload = [&](int64_t m0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int64_t m = m0 + s_row[i];
             if (m < mend) {
                 const float sc = row_scale ? row_scale[m / rps] : 1.0f;
@@ -88,54 +96,62 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const TA* __restrict__ 
     for (int64_t m0 = mbeg; m0 < mend; m0 += 64) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<uint4*>(sD + s_row[i] * WG_ROWB + s_chk[i] * 16) = rd[i];
-            *reinterpret_cast<uint4*>(sA + s_row[i] * WG_ROWB + s_chk[i] * 16) = ra[i];
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(sD + s_off[i]) = rd[i];
+            *reinterpret_cast<uint4*>(sA + s_off[i]) = ra[i];
         }
         __syncthreads();
         if (m0 + 64 < mend) gload(m0 + 64);
-        bf16x8 df[3], af[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sD + t_off + b * 64));
-            const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sD + t_off + b * 64 + 4 * WG_ROWB));
-            const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sA + t_off + b * 64));
-            const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(sA + t_off + b * 64 + 4 * WG_ROWB));
-            df[b][0] = dlo[0]; df[b][1] = dlo[1]; df[b][2] = dlo[2]; df[b][3] = dlo[3];
-            df[b][4] = dhi[0]; df[b][5] = dhi[1]; df[b][6] = dhi[2]; df[b][7] = dhi[3];
-            af[b][0] = alo[0]; af[b][1] = alo[1]; af[b][2] = alo[2]; af[b][3] = alo[3];
-            af[b][4] = ahi[0]; af[b][5] = ahi[1]; af[b][6] = ahi[2]; af[b][7] = ahi[3];
-        }
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* dp = sD + t_off + ks * 16 * WG_ROWB + wave * 64;
+            const bf16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(dp));
+            const bf16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(dp + 4 * WG_ROWB));
+            bf16x8 df;
+            df[0] = dlo[0]; df[1] = dlo[1]; df[2] = dlo[2]; df[3] = dlo[3];
+            df[4] = dhi[0]; df[5] = dhi[1]; df[6] = dhi[2]; df[7] = dhi[3];
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int kb = 0; kb < 3; ++kb)
-                acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[nb], af[kb], acc[nb][kb], 0, 0, 0);
-    }
-    // acc[nb][kb][i]: row n = 32nb + (i&3) + 8(i>>2) + 4h, col k = 32kb + r
-#pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-        for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n0 + 32 * nb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                atomicAdd(dW + (int64_t)n * K + k0 + 32 * kb + r, acc[nb][kb][i]);
+            for (int kb = 0; kb < 3; ++kb) {
+                const char* ap = sA + t_off + ks * 16 * WG_ROWB + kb * 64;
+                const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ap));
+                const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(ap + 4 * WG_ROWB));
+                bf16x8 af;
+                af[0] = alo[0]; af[1] = alo[1]; af[2] = alo[2]; af[3] = alo[3];
+                af[4] = ahi[0]; af[5] = ahi[1]; af[6] = ahi[2]; af[7] = ahi[3];
+                acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, af, acc[kb], 0, 0, 0);
             }
+            if (do_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, ones, bacc, 0, 0, 0);   // dy^T . 1 = bias gradient
+        }
+    }
+    // acc[kb][i]: row n = 32*wave + (i&3) + 8(i>>2) + 4h, col k = 32kb + r  -> 128 contiguous bytes per half-wave atomic
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(dW + (int64_t)n * K + k0 + 32 * kb + r, acc[kb][i]);
+        }
+    if (do_bias && r == 0) {   // every column of bacc holds the row sums
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(db + n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h, bacc[i]);
+    }
 }
 
 // exact fp32: 64(n) x 64(k) tile per block over an M chunk, 4x4 per thread
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy,
                                                         int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
-                                                        float* __restrict__ dW, int64_t M, int N, int K) {
+                                                        float* __restrict__ dW, float* __restrict__ db, int64_t M, int N, int K,
+                                                        int mchunk) {
     __shared__ float Ds[16][68];
     __shared__ float As[16][68];
     const int ntk = (K + 63) / 64;
     const int n0 = (blockIdx.x / ntk) * 64, k0 = (blockIdx.x % ntk) * 64;
-    const int64_t mbeg = (int64_t)blockIdx.y * WG_MCHUNK;
-    const int64_t mend = mbeg + WG_MCHUNK < M ? mbeg + WG_MCHUNK : M;
+    const int64_t mbeg = (int64_t)blockIdx.y * mchunk;
+    const int64_t mend = mbeg + mchunk < M ? mbeg + mchunk : M;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
+    const bool do_bias = db != nullptr && k0 == 0;
+    float bsum = 0.f;
     const int lm = tid >> 4, lc = (tid & 15) * 4;   // loader: row lm (0..15), 4 columns at lc
     float acc[4][4] = {};
     for (int64_t m0 = mbeg; m0 < mend; m0 += 16) {
@@ -153,6 +169,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
         *reinterpret_cast<float4*>(&Ds[lm][lc]) = dv;
         *reinterpret_cast<float4*>(&As[lm][lc]) = av;
         __syncthreads();
+        if (do_bias && tid < 64) {
+#pragma unroll
+            for (int mm = 0; mm < 16; ++mm) bsum += Ds[mm][tid];
+        }
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm) {
             const float4 d4 = *reinterpret_cast<const float4*>(&Ds[mm][ty * 4]);
@@ -172,23 +192,30 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
             const int n = n0 + ty * 4 + i, k = k0 + tx * 4 + j;
             if (n < N && k < K) atomicAdd(dW + (int64_t)n * K + k, acc[i][j]);
         }
+    if (do_bias && tid < 64 && n0 + tid < N) atomicAdd(db + n0 + tid, bsum);
 }
 
-// dW must be zeroed (or hold the value to accumulate onto) by the caller.
+// dW (and db when given: db[n] += sum_m scale*dy[m][n]) must be zeroed (or hold the value to accumulate onto) by the caller.
 extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                                 const float* row_scale, int64_t rows_per_scale, float* dW, int64_t M, int N, int K,
-                                 int act_dtype, void* stream) {
+                                 const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                                 int K, int act_dtype, void* stream) {
     if (!a || !dy || !dW || M <= 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
     if (row_scale && rows_per_scale <= 0) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
-    const int64_t mchunks = (M + WG_MCHUNK - 1) / WG_MCHUNK;
+    // M chunk per workgroup: enough workgroups to fill the chip (~2048), at least 1024 rows to amortise the atomics
+    const int64_t tiles = act_dtype == MVIT_F32 ? (int64_t)((N + 63) / 64) * ((K + 63) / 64) : (int64_t)(N / 96) * (K / 96);
+    int64_t mc = (M * (tiles > 0 ? tiles : 1) + 2047) / 2048;
+    mc = mc < WG_MCHUNK ? WG_MCHUNK : mc;
+    mc = (mc + 63) / 64 * 64;
+    const int mchunk = (int)mc;
+    const int64_t mchunks = (M + mchunk - 1) / mchunk;
     if (mchunks > 65535) return MVIT_EINVAL;
     if (act_dtype == MVIT_F32) {
         if (a_dtype != MVIT_F32 || dy_dtype != MVIT_F32) return MVIT_EDTYPE;
         if ((lda & 3) || (ldd & 3)) return MVIT_EUNSUPPORTED;
         dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)mchunks);
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
-                           rows_per_scale, dW, M, N, K);
+                           rows_per_scale, dW, db, M, N, K, mchunk);
         MVIT_LAUNCH_CHECK();
         return MVIT_OK;
     }
@@ -196,7 +223,7 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
     if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return MVIT_EUNSUPPORTED;
     dim3 grid((N / 96) * (K / 96), (unsigned)mchunks);
 #define WG(TA, TD) \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(256), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, M, N, K)
+    hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(192), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, db, M, N, K, mchunk)
     if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16) WG(bf16_t, bf16_t);
     else if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_F32) WG(bf16_t, float);
     else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_F32) WG(float, float);

@@ -239,58 +239,63 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const TA* __restrict__ 
     }
 }
 
-// dw partials: block = 4 token lanes x 192 (channel, tap-half) threads; each thread walks every 4th token of the block's
-// contiguous token range with its 13/14 taps in registers; LDS combine of the 4 lanes; one partial row [2592] per block.
+// dw partials: thread = (16-byte channel chunk, tap) -> 2 wide loads per 8 (bf16) / 4 (fp32) FMAs; 3 token lanes per block walk
+// every 3rd token of the block's contiguous token range; LDS combine; one partial row [2592] per block.
 template <typename TA>
-__global__ __launch_bounds__(768) void pool_wgrad_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
-                                                         const TA* __restrict__ dconv, float* __restrict__ part, int B,
-                                                         int heads, int T, int H, int W, int Ho, int Wo, int s) {
-    __shared__ float red[3][2592];
-    const int tl = threadIdx.x / 192, t192 = threadIdx.x % 192;
-    const int c = t192 % 96, half = t192 / 96;   // half 0: taps 0..13, half 1: taps 14..26
-    const int tap0 = half * 14, ntap = half ? 13 : 14;
+__global__ __launch_bounds__(1024) void pool_wgrad_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
+                                                          const TA* __restrict__ dconv, float* __restrict__ part, int B,
+                                                          int heads, int T, int H, int W, int Ho, int Wo, int s) {
+    constexpr int CW = 16 / sizeof(TA);
+    constexpr int NCG = 96 / CW;             // channel groups (12 bf16 / 24 fp32)
+    constexpr int NPAIR = NCG * 27;          // (cg, tap) pairs: 324 / 648
+    constexpr int TL = 1024 / NPAIR;         // token lanes: 3 / 1
+    __shared__ float red[(TL > 1 ? TL - 1 : 1)][2592];
+    const int tl = threadIdx.x / NPAIR, pr = threadIdx.x % NPAIR;
+    const bool on = tl < TL;
+    const int cg = pr % NCG, tap = pr / NCG;
+    const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
     const int64_t Lout = (int64_t)T * Ho * Wo;
     const int64_t total = (int64_t)B * heads * Lout;
     const int64_t Nin = (int64_t)T * H * W;
-    float acc[14];
+    float acc[CW];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) acc[k] = 0.f;
+    for (int e = 0; e < CW; ++e) acc[e] = 0.f;
     const int64_t per = (total + gridDim.x - 1) / gridDim.x;
     const int64_t beg = (int64_t)blockIdx.x * per;
     const int64_t end = beg + per < total ? beg + per : total;
-    for (int64_t it = beg + tl; it < end; it += 4) {
-        int64_t rem = it;
-        const int xo = (int)(rem % Wo); rem /= Wo;
-        const int yo = (int)(rem % Ho); rem /= Ho;
-        const int to = (int)(rem % T); rem /= T;
-        const int gh = (int)(rem % heads);
-        const int b = (int)(rem / heads);
-        const float d = ActIO<TA>::load(dconv + it * 96 + c);
-        const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + gh * 96 + c;
+    if (on)
+        for (int64_t it = beg + tl; it < end; it += TL) {
+            int64_t rem = it;
+            const int xo = (int)(rem % Wo); rem /= Wo;
+            const int yo = (int)(rem % Ho); rem /= Ho;
+            const int to = (int)(rem % T); rem /= T;
+            const int gh = (int)(rem % heads);
+            const int b = (int)(rem / heads);
+            const int ti = to + dt - 1, yi = yo * s + dy - 1, xi = xo * s + dx - 1;
+            if (ti < 0 || ti >= T || yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+            const TA* ip = qkv + ((int64_t)b * Nin + ((int64_t)ti * H + yi) * W + xi) * ld + chan_off + gh * 96 + CW * cg;
+            const TA* dp = dconv + it * 96 + CW * cg;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) {
-            if (k < ntap) {
-                const int tap = tap0 + k;
-                const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                const int ti = to + dt - 1, yi = yo * s + dy - 1, xi = xo * s + dx - 1;
-                if (ti >= 0 && ti < T && yi >= 0 && yi < H && xi >= 0 && xi < W)
-                    acc[k] = fmaf(d, ActIO<TA>::load(base + (((int64_t)ti * H + yi) * W + xi) * ld), acc[k]);
+            for (int e = 0; e < CW; e += 4) {
+                const float4 d4 = load4(dp + e), v4 = load4(ip + e);
+                acc[e] = fmaf(d4.x, v4.x, acc[e]); acc[e + 1] = fmaf(d4.y, v4.y, acc[e + 1]);
+                acc[e + 2] = fmaf(d4.z, v4.z, acc[e + 2]); acc[e + 3] = fmaf(d4.w, v4.w, acc[e + 3]);
             }
         }
-    }
-    if (tl > 0) {
+    if (on && tl > 0) {
 #pragma unroll
-        for (int k = 0; k < 14; ++k)
-            if (k < ntap) red[tl - 1][c * 27 + tap0 + k] = acc[k];
+        for (int e = 0; e < CW; ++e) red[tl - 1][(CW * cg + e) * 27 + tap] = acc[e];
     }
     __syncthreads();
     if (tl == 0) {
 #pragma unroll
-        for (int k = 0; k < 14; ++k)
-            if (k < ntap) {
-                const int o = c * 27 + tap0 + k;
-                part[(int64_t)blockIdx.x * 2592 + o] = acc[k] + red[0][o] + red[1][o] + red[2][o];
-            }
+        for (int e = 0; e < CW; ++e) {
+            const int o = (CW * cg + e) * 27 + tap;
+            float t = acc[e];
+#pragma unroll
+            for (int k = 0; k < TL - 1; ++k) t += red[k][o];
+            part[(int64_t)blockIdx.x * 2592 + o] = t;
+        }
     }
 }
 
@@ -327,7 +332,7 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
     MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(768), 0, st, (const TA*)qkv, ld, chan_off,         \
+    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, st, (const TA*)qkv, ld, chan_off,         \
                        (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                     \
     MVIT_LAUNCH_CHECK();                                                                                                   \
     hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, (int)b3, 2592, dw, dw, 2592, 1);              \

@@ -124,11 +124,12 @@ int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int d
 int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
 int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
 
-/* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight).  dy rows may carry the per-sample
- * drop-path factor row_scale[m / rows_per_scale].  dW is accumulated into (zero it once per step). */
+/* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight) and, when db != NULL, db[n] += sum_m dy[m][n]
+ * (bias gradient, fused: the dy tile is already on chip).  dy rows may carry the per-sample drop-path factor
+ * row_scale[m / rows_per_scale].  dW / db are accumulated into (zero them once per step). */
 int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                      const float* row_scale, int64_t rows_per_scale, float* dW, int64_t M, int N, int K,
-                      int act_dtype, void* stream);
+                      const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                      int K, int act_dtype, void* stream);
 
 /* out[n] (+)= sum_m row_scale[m/rps] * a[m][n]  (bias gradients).  workspace >= mvit_colsum_workspace_bytes(N). */
 int64_t mvit_colsum_workspace_bytes(int N);

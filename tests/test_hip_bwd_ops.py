@@ -107,11 +107,13 @@ def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
         ref = dys_m.t() @ a.float()
         base = _rnd(N, K, seed=13)
         dW = base.clone().to(DEV)
+        dbf = torch.zeros(N, device=DEV)
         ad, dyd = a.to(DEV), dy.to(DEV)
         scd = sc.to(DEV) if scaled else None
         _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(ad), act, K, _hip.ptr(dyd), _hip.F32 if dy_f32 else _hip.BF16, N,
-                                             _hip.ptr(scd), rps if scaled else 0, _hip.ptr(dW), M, N, K, act, _st()))
+                                             _hip.ptr(scd), rps if scaled else 0, _hip.ptr(dW), _hip.ptr(dbf), M, N, K, act, _st()))
         _close(dW, ref + base, 2e-3 if act else 2e-5)
+        _close(dbf, dys_m.sum(0), 2e-3 if act else 2e-5)
         ws = torch.empty(hip_lib.mvit_colsum_workspace_bytes(N) // 4, device=DEV)
         db = torch.zeros(N, device=DEV)
         _hip.check(hip_lib.mvit_colsum(_hip.ptr(dyd), _hip.F32 if dy_f32 else _hip.BF16, M, N, _hip.ptr(scd),
