@@ -218,7 +218,7 @@ class _BlockFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dk = torch.empty_like(k)
         dv = torch.empty_like(v)
-        ws = _ws(L.mvit_attention_bwd_workspace_bytes(B, h, Lq), dev)
+        ws = _ws(L.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk), dev)
         _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(d_o), _hip.ptr(dq),
                                         _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
                    "attention_bwd")

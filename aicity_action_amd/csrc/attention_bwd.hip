@@ -215,10 +215,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------------
 // pass B (bf16 MFMA): dK, dV.   grid (ceil(Lk/128), B*heads), 4 waves x 32 keys; streams 64-query tiles.
 // ------------------------------------------------------------------------------------------------
+// SPLIT: gridDim.z workgroups share one key block, each sweeping a slice of the queries and adding its partial dK/dV into
+// fp32 buffers (dKf/dVf, zeroed by the launcher) -- used when B*heads*ceil(Lk/128) alone cannot fill the chip (block 0).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int heads,
+                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
+                                                           float* __restrict__ dKf, float* __restrict__ dVf, int heads,
                                                            int Lq, int Lk, float scale, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) char smem[4 * B_T * B_ROWB + 2 * B_T * 4];
     char* sQ = smem;                        // rotation image (row reads)
@@ -286,9 +290,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
-    const int nqt = (Lq + B_T - 1) / B_T;
-    gload(0);
-    for (int qt = 0; qt < nqt; ++qt) {
+    const int nqt_all = (Lq + B_T - 1) / B_T;
+    const int per_z = (nqt_all + gridDim.z - 1) / gridDim.z;
+    const int qt_beg = SPLIT ? blockIdx.z * per_z : 0;
+    const int nqt = SPLIT ? (qt_beg + per_z < nqt_all ? qt_beg + per_z : nqt_all) : nqt_all;
+    gload(qt_beg * B_T);
+    for (int qt = qt_beg; qt < nqt; ++qt) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -351,6 +358,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf[s16], dv[db], 0, 0, 0);
                 dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[s16], dk[db], 0, 0, 0);
             }
+    }
+    if (SPLIT) {
+        if (k_ok) {
+            float* krow = dKf + ((int64_t)bh * Lk + ki) * 96;
+            float* vrow = dVf + ((int64_t)bh * Lk + ki) * 96;
+#pragma unroll
+            for (int db = 0; db < 3; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int d = 32 * db + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    atomicAdd(krow + d, dk[db][i] * scale);
+                    atomicAdd(vrow + d, dv[db][i]);
+                }
+        }
+        return;
     }
     if (k_ok) {
         bf16_t* krow = dK + ((int64_t)bh * Lk + ki) * 96;
@@ -501,8 +523,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(256) void cast2_bf16_kernel(const float* __restrict__ a, bf16_t* __restrict__ oa, const float* __restrict__ b,
+                                                         bf16_t* __restrict__ ob, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        store4(oa + 4 * i, load4(a + 4 * i));
+        store4(ob + 4 * i, load4(b + 4 * i));
+    }
+}
+
+static int dkv_splits(int B, int heads, int Lq, int Lk) {
+    const int64_t base = (int64_t)B * heads * ((Lk + 127) / 128);
+    if (base >= 384) return 1;
+    int64_t z = (768 + base - 1) / base;
+    const int64_t maxz = (Lq + 1023) / 1024;      // at least 1024 queries per slice
+    if (z > maxz) z = maxz;
+    return (int)(z < 1 ? 1 : z);
+}
+
+// delta [B*heads*Lq] + (split path) fp32 dK, dV partial sums [2][B*heads*Lk*96]
+extern "C" int64_t mvit_attention_bwd_workspace_bytes2(int B, int heads, int Lq, int Lk) {
+    return ((int64_t)B * heads * Lq + 2ll * B * heads * Lk * 96) * (int64_t)sizeof(float);
+}
 extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq) {
-    return (int64_t)B * heads * Lq * (int64_t)sizeof(float);
+    return mvit_attention_bwd_workspace_bytes2(B, heads, Lq, 6272);
 }
 
 // q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.
@@ -531,9 +574,25 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
         MVIT_LAUNCH_CHECK();
+        const int nz = dkv_splits(B, heads, Lq, Lk);
+        if (nz > 1) {
+            float* dkf = workspace + rows;
+            const int64_t nkv = (int64_t)B * heads * Lk * 96;
+            float* dvf = dkf + nkv;
+            if (hipMemsetAsync(dkf, 0, 2 * nkv * sizeof(float), st) != hipSuccess) return MVIT_ELAUNCH;
+            dim3 gk((Lk + 127) / 128, B * heads, nz);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale, sl2);
+            MVIT_LAUNCH_CHECK();
+            int64_t cb = (nkv / 4 + 255) / 256;
+            if (cb > 4096) cb = 4096;
+            hipLaunchKernelGGL(cast2_bf16_kernel, dim3((unsigned)cb), dim3(256), 0, st, dkf, (bf16_t*)dk, dvf, (bf16_t*)dv, nkv / 4);
+            MVIT_LAUNCH_CHECK();
+            return MVIT_OK;
+        }
         dim3 gk((Lk + 127) / 128, B * heads);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                           (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, heads, Lq, Lk, scale, sl2);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                           (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale, sl2);
         MVIT_LAUNCH_CHECK();
         return MVIT_OK;
     }

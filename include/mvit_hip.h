@@ -138,8 +138,10 @@ int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_s
 
 /* Backward of mvit_attention_fwd (recompute from LSE; deterministic, no atomics).
  * out / dout: [B][Lq][heads*96]; dq [B][heads][Lq][96]; dk, dv [B][heads][Lk][96]; all act-typed.
- * workspace >= mvit_attention_bwd_workspace_bytes(B, heads, Lq). */
-int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq);
+ * workspace >= mvit_attention_bwd_workspace_bytes2(B, heads, Lq, Lk)  (delta + fp32 dK/dV partial sums for the
+ * query-split variant used when B*heads*ceil(Lk/128) workgroups cannot fill the chip). */
+int64_t mvit_attention_bwd_workspace_bytes2(int B, int heads, int Lq, int Lk);
+int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq);   /* = ..._bytes2(B, heads, Lq, 6272) */
 int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                        const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);

@@ -123,7 +123,7 @@ def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(1, 1, 128, 64, 1), (2, 2, 100, 33, 1), (1, 2, 257, 392, 0), (1, 4, 392, 1568, 1),
-                                               (2, 1, 64, 200, 1)])
+                                               (2, 1, 64, 200, 1), (1, 1, 5000, 200, 1)])
 def test_attention_bwd(hip_lib, act, B, h, Lq, Lk, add_q):
     scale = 96 ** -0.5
     q = _act(_rnd(B, h, Lq, 96, seed=14), act)
@@ -146,7 +146,7 @@ def test_attention_bwd(hip_lib, act, B, h, Lq, Lk, add_q):
     lse_ref = torch.logsumexp((qr.detach() @ kr.detach().transpose(-2, -1)) * scale, -1) * 1.4426950408889634
     _close(lse, lse_ref, 1e-2 if act else 1e-5)
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq) // 4, device=DEV)
+    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk) // 4, device=DEV)
     _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod),
                                           _hip.ptr(dq), _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, add_q,
                                           act, _st()))
