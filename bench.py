@@ -120,43 +120,67 @@ def main():
     assert torch.isfinite(out).all()
     clips_per_s = world * args.batch * args.steps / dt
 
-    # ---- dominant kernel (fused attention): live HIP-event timing on the launch stream --------------------
+    # ---- dominant kernel family (fused attention): live HIP-event timing on the launch stream -------------------
+    # fwd mode : attn_fwd kernel, algorithmic FLOPs = sum_blocks 4*B*h*Lq*Lk*96.
+    # train    : the attention backward (delta + dQ pass + dK/dV pass per block) is the largest item of the step;
+    #            algorithmic FLOPs = 2x the forward's (train = 3x forward, recompute not credited).
     roofline = None
+    extra_rooflines = {}
     if rank == 0 and not args.no_kernel_timing:
         L = _hip.lib()
         act = _hip.BF16 if args.precision == "bf16" else _hip.F32
         adt = torch.bfloat16 if act == _hip.BF16 else torch.float32
         st = torch.cuda.current_stream().cuda_stream
         flops = attention_flops(core.geoms, args.batch)
-        tot_ms = 0.0
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         reps = 5
-        per_block = []
-        for gm, fl in zip(core.geoms, flops):
-            q = torch.randn(args.batch, gm.heads, gm.lq, 96, device=dev).to(adt)
-            k = torch.randn(args.batch, gm.heads, gm.lk, 96, device=dev).to(adt)
-            v = torch.randn(args.batch, gm.heads, gm.lk, 96, device=dev).to(adt)
-            o = torch.empty(args.batch, gm.lq, gm.heads * 96, device=dev, dtype=adt)
 
-            def run():
-                _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), None, args.batch, gm.heads,
-                                                gm.lq, gm.lk, 96 ** -0.5, 1, act, st))
-            run()
+        def timed(fn):
+            fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                run()
+                fn()
             e1.record()
             e1.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            tot_ms += ms
-            per_block.append(round(fl / ms / 1e9, 1))
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        achieved = sum(flops) / (tot_ms * 1e-3) / 1e12
-        roofline = {"kernel": "attn_fwd_%s_kernel" % ("bf16" if act else "f32"), "bound": "mfma",
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": None, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
-                    "algorithmic_gflop_per_launch_avg": round(sum(flops) / len(flops) / 1e9, 2),
-                    "tflops_per_block": per_block}
+            return e0.elapsed_time(e1) / reps
+
+        fwd_ms, bwd_ms, per_f, per_b = 0.0, 0.0, [], []
+        for gm, fl in zip(core.geoms, flops):
+            B_, h_ = args.batch, gm.heads
+            q = torch.randn(B_, h_, gm.lq, 96, device=dev).to(adt)
+            k = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
+            v = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
+            o = torch.empty(B_, gm.lq, h_ * 96, device=dev, dtype=adt)
+            lse = torch.empty(B_, h_, gm.lq, device=dev)
+            ms = timed(lambda: _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B_, h_,
+                                                                gm.lq, gm.lk, 96 ** -0.5, 1, act, st)))
+            fwd_ms += ms
+            per_f.append(round(fl / ms / 1e9, 1))
+            if train:
+                do = torch.randn(B_, gm.lq, h_ * 96, device=dev).to(adt)
+                dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+                ws = torch.empty(L.mvit_attention_bwd_workspace_bytes2(B_, h_, gm.lq, gm.lk) // 4, device=dev)
+                ms = timed(lambda: _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse),
+                                                                    _hip.ptr(do), _hip.ptr(dq), _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws),
+                                                                    B_, h_, gm.lq, gm.lk, 96 ** -0.5, 1, act, st)))
+                bwd_ms += ms
+                per_b.append(round(2 * fl / ms / 1e9, 1))
+                del do, dq, dk, dv, ws
+            del q, k, v, o, lse
+
+        def rl(name, tot_flops, tot_ms, per_block):
+            ach = tot_flops / (tot_ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
+                    "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
+        sfx = "bf16" if act else "f32"
+        fwd_rl = rl("attn_fwd_%s_kernel" % sfx, sum(flops), fwd_ms, per_f)
+        if train:
+            roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b)
+            extra_rooflines["roofline_attention_fwd"] = fwd_rl
+        else:
+            roofline = fwd_rl
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample ------------------------------------------
     cpu = None
@@ -166,17 +190,46 @@ def main():
         cores = min(os.cpu_count() or 1, 32)     # more threads than this slows the oracle down on a 256-core host
         torch.set_num_threads(cores)
         sd = {k: v.detach().cpu() for k, v in core.state_dict().items()}
-        c1 = clip[:1].cpu()
-        n_timed = 1 if args.crop == 448 else 8
-        with torch.no_grad():
-            O.forward(sd, c1, mv)                      # warm-up
-            t0 = time.perf_counter()
-            for _ in range(n_timed):
-                O.forward(sd, c1, mv)
-            cdt = time.perf_counter() - t0
+        crop_cpu = args.crop
+        if train:
+            import psutil
+            if args.crop == 448 and psutil.virtual_memory().available < 96 * 2 ** 30:
+                crop_cpu = 224      # fp32 autograd of the unfused path keeps ~20 GB of score matrices per clip @448
+        if crop_cpu != args.crop:
+            ycpu = "MVITV2_FULL_B_16x4_CONV.yaml"
+            cfg_cpu = load_config(os.path.join(ROOT, "configs", "Aicity", ycpu), ["NUM_GPUS", 0])
+            from aicity_action_amd.utils.synth import synth_state_dict
+            from aicity_action_amd.models.mvit import MViT as _M
+            sd = synth_state_dict({k_: v_.shape for k_, v_ in _M(cfg_cpu).state_dict().items()}, 0)
+            mv_cpu = copy.deepcopy(cfg_cpu.MVIT.to_dict())
+            c1 = torch.randn(1, 3, 16, 224, 224)
+        else:
+            mv_cpu = mv
+            c1 = clip[:1].cpu()
+        n_timed = 1 if crop_cpu == 448 else 4
+        if train:
+            mv_cpu = dict(mv_cpu, DROPPATH_RATE=0.0)
+            y1 = torch.zeros(1, cfg.MODEL.NUM_CLASSES)
+            y1[0, 0] = 1.0
+            sdg = {k_: v_.clone().requires_grad_(True) for k_, v_ in sd.items()}
+
+            def cpu_step():
+                out, _ = O.forward(sdg, c1, mv_cpu, training=True)
+                O.soft_target_cross_entropy(out, y1).backward()
+            kind_txt = "forward+backward (torch autograd over the oracle)"
+        else:
+            def cpu_step():
+                with torch.no_grad():
+                    O.forward(sd, c1, mv_cpu)
+            kind_txt = "forward"
+        if crop_cpu != 448:
+            cpu_step()                                 # warm-up (skipped @448 to bound the sample)
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            cpu_step()
+        cdt = time.perf_counter() - t0
         cpu = {"value": round(n_timed / cdt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-               "sample": "%d x forward B=1 @%d fp32 (oracle/mvit_oracle.py, torch CPU, %d threads) after 1 warm-up"
-                         % (n_timed, args.crop, cores)}
+               "sample": "%d x %s B=1 @%d fp32 (oracle/mvit_oracle.py, torch CPU, %d threads)" % (n_timed, kind_txt, crop_cpu, cores)}
 
     if rank == 0:
         gf = GFLOP_PER_CLIP[args.crop] * (3.0 if train else 1.0)   # train step = 3x forward FLOPs
@@ -197,6 +250,7 @@ def main():
                                "unit": "TFLOP/s", "frac": round(clips_per_s / world * gf / 1e3 / peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        line.update(extra_rooflines)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
