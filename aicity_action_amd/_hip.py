@@ -45,6 +45,7 @@ _SIGS = {
     "mvit_attention_bwd_workspace_bytes2": (c_l, [c_i, c_i, c_i, c_i]),
     "mvit_attention_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "mvit_pool_bwd_workspace_bytes": (c_l, []),
+    "mvit_pool_bwd_workspace_bytes2": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_maxpool_skip_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -224,7 +224,8 @@ class _BlockFn(torch.autograd.Function):
                    "attention_bwd")
         del d_o
         d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)
-        pws = _ws(L.mvit_pool_bwd_workspace_bytes(), dev)
+        pws = _ws(max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1]),
+                      L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1])), dev)
         pool_grads = []
         for which, (dbuf, conv, norm, stride) in enumerate(((dq, at.pool_q, at.norm_q, g.stride_q[1]),
                                                             (dk, at.pool_k, at.norm_k, g.stride_kv[1]),

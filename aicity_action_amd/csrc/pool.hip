@@ -168,12 +168,17 @@ struct PoolTile {
     static constexpr int SMEM = NBUF * IN_BYTES + NTOK * 96 * 4 + W_BYTES;
 };
 
-template <typename TA, int S>
+// BWD = true: the same march recomputes the conv + LayerNorm statistics and applies the LayerNorm BACKWARD in the finalize
+// step: `out` then receives d_conv (gradient wrt the conv output), `dout` is the incoming gradient, and per-block partial
+// sums of d_gamma / d_beta go to part[block][192] (accumulated in LDS with ds_add_f32).
+template <typename TA, int S, bool BWD>
 __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     const TA* __restrict__ qkv, int64_t ld, int chan_off, const float* __restrict__ w, const float* __restrict__ gamma,
-    const float* __restrict__ beta, TA* __restrict__ out, int heads, int T, int H, int W, int Ho, int Wo, float eps) {
+    const float* __restrict__ beta, TA* __restrict__ out, const TA* __restrict__ dout, float* __restrict__ part, int heads,
+    int T, int H, int W, int Ho, int Wo, float eps) {
     using P = PoolTile<TA, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float dgam = 0.f;   // BWD: threads < 96 own one channel of the d_gamma partial (d_beta = column sum of dout, done by the caller)
     float* stage = reinterpret_cast<float*>(smem + P::NBUF * P::IN_BYTES);
 
     const int tid = threadIdx.x;
@@ -262,8 +267,50 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
             sq += __shfl_xor(sq, 2, 64);
             const float rstd = 1.0f / sqrtf(sq * (1.0f / 96.0f) + eps);
             const int yo = ty0 + ltok / P::XO, xo = tx0 + ltok % P::XO;
-            if (yo < Ho && xo < Wo) {
-                TA* o = out + (((int64_t)bh * T + fo) * Ho * Wo + (int64_t)yo * Wo + xo) * 96;
+            const bool tok_ok = yo < Ho && xo < Wo;
+            const int64_t orow = (((int64_t)bh * T + fo) * Ho * Wo + (int64_t)yo * Wo + xo) * 96;
+            if (BWD) {
+                float dyv[24];
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < CW; e += 4) {
+                        float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (tok_ok) d4 = load4(dout + orow + CW * (lj + 4 * i) + e);
+                        dyv[i * CW + e] = d4.x; dyv[i * CW + e + 1] = d4.y; dyv[i * CW + e + 2] = d4.z; dyv[i * CW + e + 3] = d4.w;
+                    }
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        const int k = i * CW + e, c = CW * (lj + 4 * i) + e;
+                        v[k] *= rstd;                                   // xhat
+                        stage[ltok * 96 + c] = dyv[k] * v[k];           // dy * xhat -> column sums below (dy = 0 for padded tokens)
+                        dyv[k] *= gamma[c];
+                        c1 += dyv[k];
+                        c2 += dyv[k] * v[k];
+                    }
+                c1 += __shfl_xor(c1, 1, 64); c1 += __shfl_xor(c1, 2, 64);
+                c2 += __shfl_xor(c2, 1, 64); c2 += __shfl_xor(c2, 2, 64);
+                c1 *= (1.0f / 96.0f);
+                c2 *= (1.0f / 96.0f);
+                if (tok_ok) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) {
+                            const int k = i * CW + e;
+                            float4 r;
+                            r.x = rstd * (dyv[k] - c1 - v[k] * c2);
+                            r.y = rstd * (dyv[k + 1] - c1 - v[k + 1] * c2);
+                            r.z = rstd * (dyv[k + 2] - c1 - v[k + 2] * c2);
+                            r.w = rstd * (dyv[k + 3] - c1 - v[k + 3] * c2);
+                            store4(out + orow + CW * (lj + 4 * i) + e, r);
+                        }
+                }
+            } else if (tok_ok) {
+                TA* o = out + orow;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
                     const int c0 = CW * (lj + 4 * i);
@@ -277,6 +324,13 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
                         store4(o + c0 + e, r);
                     }
                 }
+            }
+        }
+        if (BWD) {
+            __syncthreads();
+            if (tid < 96) {
+#pragma unroll 8
+                for (int tk = 0; tk < P::NTOK; ++tk) dgam += stage[tk * 96 + tid];
             }
         }
     };
@@ -327,6 +381,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
         }
     }
     finalize(T - 1);
+    if (BWD && tid < 96) part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 96 + tid] = dgam;
 }
 
 template <typename TA, int S>
@@ -337,15 +392,54 @@ static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const fl
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((pool_tiled_kernel<TA, S>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
-                       beta, (TA*)out, heads, T, H, W, Ho, Wo, eps);
+    hipLaunchKernelGGL((pool_tiled_kernel<TA, S, false>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
+                       beta, (TA*)out, (const TA*)nullptr, (float*)nullptr, heads, T, H, W, Ho, Wo, eps);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+
+template <typename TA, int S>
+static int launch_pool_tiled_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
+                                 void* dconv, float* part, int B, int heads, int T, int H, int W, int Ho, int Wo, float eps,
+                                 hipStream_t st) {
+    using P = PoolTile<TA, S>;
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pool_tiled_kernel<TA, S, true>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
+                       gamma, (TA*)dconv, (const TA*)dout, part, heads, T, H, W, Ho, Wo, eps);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// internal (used by pool_bwd.hip): LN-backward of the pooled conv through the tiled march; returns the number of partial rows
+// written to part ([rows][96], d_gamma only) or a negative error.  Only strides 1 and 2.
+int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
+                                    void* dconv, float* part, int B, int heads, int T, int H, int W, int stride_hw, float eps,
+                                    int act_dtype, hipStream_t st) {
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    int rc;
+    int rows;
+    if (stride_hw == 1) {
+        rows = ((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
+        rc = act_dtype == MVIT_BF16 ? launch_pool_tiled_bwd<bf16_t, 1>(qkv, ld, chan_off, w, gamma, dout, dconv, part, B, heads, T, H, W, Ho, Wo, eps, st)
+                                    : launch_pool_tiled_bwd<float, 1>(qkv, ld, chan_off, w, gamma, dout, dconv, part, B, heads, T, H, W, Ho, Wo, eps, st);
+    } else {
+        rows = ((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
+        rc = act_dtype == MVIT_BF16 ? launch_pool_tiled_bwd<bf16_t, 2>(qkv, ld, chan_off, w, gamma, dout, dconv, part, B, heads, T, H, W, Ho, Wo, eps, st)
+                                    : launch_pool_tiled_bwd<float, 2>(qkv, ld, chan_off, w, gamma, dout, dconv, part, B, heads, T, H, W, Ho, Wo, eps, st);
+    }
+    return rc < 0 ? rc : rows;
 }
 
 extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,

@@ -9,6 +9,12 @@
 #define PB_MAXBLK 256
 #define PW_MAXBLK 512
 
+extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_scale, int64_t rows_per_scale,
+                           float* out, int accumulate, float* workspace, void* stream);
+int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
+                                    void* dconv, float* part, int B, int heads, int T, int H, int W, int stride_hw, float eps,
+                                    int act_dtype, hipStream_t st);
+
 template <typename TA>
 __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
                                                           const float* __restrict__ w, const float* __restrict__ gamma,
@@ -300,6 +306,16 @@ __global__ __launch_bounds__(1024) void pool_wgrad_kernel(const TA* __restrict__
 }
 
 extern "C" int64_t mvit_pool_bwd_workspace_bytes(void) { return ((int64_t)PB_MAXBLK * 192 + (int64_t)PW_MAXBLK * 2592) * sizeof(float); }
+// geometry-aware size (the tiled LN-backward writes one 192-float partial row per tile workgroup)
+extern "C" int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H, int W, int stride_hw) {
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    int64_t rows = PB_MAXBLK;
+    if (stride_hw == 1) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
+    if (stride_hw == 2) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
+    if (rows < PB_MAXBLK) rows = PB_MAXBLK;
+    (void)T;
+    return (rows * 192 + (int64_t)PW_MAXBLK * 2592) * (int64_t)sizeof(float);
+}
 
 // dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.
 // dw [96][27] fp32 is ACCUMULATED into (caller zeroes it once per step); dgamma/dbeta: accumulate flag.
@@ -322,13 +338,29 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     if (b2 > 16384) b2 = 16384;
     int64_t b3 = (tot_out + 255) / 256;      // >= 256 tokens per block
     if (b3 > PW_MAXBLK) b3 = PW_MAXBLK;
-    float* wpart = workspace + (int64_t)PB_MAXBLK * 192;
+    int64_t prow = PB_MAXBLK;
+    if (stride_hw == 1) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
+    if (stride_hw == 2) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
+    if (prow < PB_MAXBLK) prow = PB_MAXBLK;
+    float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes2
+    const bool tiled = stride_hw == 1 || stride_hw == 2;
 #define RUN(TA)                                                                                                            \
-    hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w,     \
-                       gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);          \
-    MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3(3), dim3(256), 0, st, workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param); \
-    MVIT_LAUNCH_CHECK();                                                                                                   \
+    if (tiled) {                                                                                                           \
+        const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
+                                                          H, W, stride_hw, eps, act_dtype, st);                            \
+        if (nrows < 0) return nrows;                                                                                       \
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, nrows, 96, dgamma, dgamma, 96, accumulate_param); \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+        /* d_beta = column sums of dout (workspace rows are free again after the reduce above, same stream) */             \
+        const int rcb = mvit_colsum(dout, act_dtype, tot_out, 96, nullptr, 0, dbeta, accumulate_param, workspace, stream);  \
+        if (rcb != MVIT_OK) return rcb;                                                                                    \
+    } else {                                                                                                               \
+        hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w, \
+                           gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);      \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3(3), dim3(256), 0, st, workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param); \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+    }                                                                                                                      \
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
     MVIT_LAUNCH_CHECK();                                                                                                   \

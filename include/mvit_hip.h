@@ -148,8 +148,9 @@ int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* 
 
 /* Backward of mvit_pool_conv_ln_fwd: dout [B][heads][T*Ho*Wo][96] -> the (which) slice of dqkv [B][T*H*W][ld]
  * (fully overwritten), dw [96][27] (accumulated), dgamma/dbeta.  dconv: scratch shaped like dout.
- * workspace >= mvit_pool_bwd_workspace_bytes(). */
-int64_t mvit_pool_bwd_workspace_bytes(void);
+ * workspace >= mvit_pool_bwd_workspace_bytes2(B, heads, T, H, W, stride_hw). */
+int64_t mvit_pool_bwd_workspace_bytes(void);   /* legacy constant size: valid only for stride_hw > 2 */
+int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H, int W, int stride_hw);
 int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
                           const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
                           int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,

@@ -178,7 +178,7 @@ def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
     dconv = torch.empty(B, h, Lo, 96, dtype=adt, device=DEV)
     dw = torch.zeros(96, 27, device=DEV)
     dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
-    ws = torch.empty(hip_lib.mvit_pool_bwd_workspace_bytes() // 4, device=DEV)
+    ws = torch.empty(hip_lib.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, s) // 4, device=DEV)
     qd, wd, gd, dod = qkv.to(DEV), w.detach().to(DEV), g.detach().to(DEV), dout.to(DEV)
     _hip.check(hip_lib.mvit_pool_conv_ln_bwd(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(dod),
                                              _hip.ptr(dconv), _hip.ptr(dqkv), _hip.ptr(dw), _hip.ptr(dg), _hip.ptr(db), 0,
