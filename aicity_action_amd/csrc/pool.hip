@@ -422,6 +422,152 @@ static int launch_pool_tiled_bwd(const void* qkv, int64_t ld, int chan_off, cons
     return MVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the pooling conv through the same tiled march:
+//   dw[c][dt][dy][dx] = sum_tokens d_conv[(to,yo,xo)][c] * in[(to+dt-1, S*yo+dy-1, S*xo+dx-1)][c]
+// LDS holds the current input frame's halo tile and a 3-deep ring of d_conv frame tiles (f-1, f, f+1); thread =
+// (channel pair, output row) keeps its 27x2 partial sums in registers over all frames; combined per block with
+// ds_add_f32, one partial row [2592] per workgroup, reduced by pool_reduce in pool_bwd.hip.
+// ------------------------------------------------------------------------------------------------
+template <typename TA, int S>
+__global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel(
+    const TA* __restrict__ qkv, int64_t ld, int chan_off, const TA* __restrict__ dconv, float* __restrict__ part, int heads,
+    int T, int H, int W, int Ho, int Wo) {
+    using P = PoolTile<TA, S>;
+    constexpr int DT_BYTES = P::NTOK * 96 * (int)sizeof(TA);     // one d_conv frame tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* in_lds = smem;                                         // [IH*IW][96]
+    char* dc_lds = smem + P::IN_BYTES;                           // [3][NTOK][96]
+    const int tid = threadIdx.x;
+    const int cp = tid % 48, row = tid / 48;
+    const int tiles_x = (Wo + P::XO - 1) / P::XO;
+    const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const int64_t Nin = (int64_t)T * H * W;
+    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + g * 96;
+    const TA* dbase = dconv + (int64_t)bh * T * Ho * Wo * 96;
+    const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
+    constexpr int CW = P::CW;
+
+    auto load_in = [&](int f) {
+        for (int c = tid; c < P::NCHUNK; c += P::NT) {
+            const int tok = c / P::CPT, ch = c - tok * P::CPT;
+            const int iy = tok / P::IW, ix = tok - iy * P::IW;
+            const int y = y_in0 + iy, x = x_in0 + ix;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (y >= 0 && y < H && x >= 0 && x < W)
+                v = *reinterpret_cast<const uint4*>(base + (((int64_t)f * H + y) * W + x) * ld + ch * CW);
+            *reinterpret_cast<uint4*>(in_lds + c * 16) = v;
+        }
+    };
+    auto load_dc = [&](int fo) {     // d_conv frame fo -> ring slot fo % 3 (zeros outside the image / frame range)
+        char* dst = dc_lds + (fo % 3) * DT_BYTES;
+        for (int c = tid; c < P::NTOK * P::CPT; c += P::NT) {
+            const int tok = c / P::CPT, ch = c - tok * P::CPT;
+            const int yo = ty0 + tok / P::XO, xo = tx0 + tok % P::XO;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (fo >= 0 && fo < T && yo < Ho && xo < Wo)
+                v = *reinterpret_cast<const uint4*>(dbase + (((int64_t)fo * Ho + yo) * Wo + xo) * 96 + ch * CW);
+            *reinterpret_cast<uint4*>(dst + c * 16) = v;
+        }
+    };
+
+    float acc[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t][0] = acc[t][1] = 0.f;
+
+    load_in(0);
+    load_dc(0);
+    if (T > 1) load_dc(1);
+    __syncthreads();
+    for (int f = 0; f < T; ++f) {
+        // d_conv rows of this thread for output frames f+1, f, f-1  (tap dt = 0, 1, 2)
+        float d[3][P::XO][2];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int fo = f + 1 - dt;
+            const bool ok = fo >= 0 && fo < T;
+            const TA* dp = reinterpret_cast<const TA*>(dc_lds + ((fo + 3) % 3) * DT_BYTES) + (row * P::XO) * 96 + 2 * cp;
+#pragma unroll
+            for (int x = 0; x < P::XO; ++x) {
+                d[dt][x][0] = 0.f; d[dt][x][1] = 0.f;
+                if (ok) load2<TA>(dp + x * 96, d[dt][x][0], d[dt][x][1]);
+            }
+        }
+        const TA* tile = reinterpret_cast<const TA*>(in_lds) + 2 * cp;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            float xin[P::IW][2];
+            const TA* rp = tile + (S * row + dy) * P::IW * 96;
+#pragma unroll
+            for (int ix = 0; ix < P::IW; ++ix) load2<TA>(rp + ix * 96, xin[ix][0], xin[ix][1]);
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float a0 = acc[(dt * 3 + dy) * 3 + dx][0], a1 = acc[(dt * 3 + dy) * 3 + dx][1];
+#pragma unroll
+                    for (int x = 0; x < P::XO; ++x) {
+                        a0 = fmaf(d[dt][x][0], xin[S * x + dx][0], a0);
+                        a1 = fmaf(d[dt][x][1], xin[S * x + dx][1], a1);
+                    }
+                    acc[(dt * 3 + dy) * 3 + dx][0] = a0;
+                    acc[(dt * 3 + dy) * 3 + dx][1] = a1;
+                }
+        }
+        __syncthreads();                       // everyone is done with the input tile and with d_conv frame f-1
+        if (f + 1 < T) {
+            load_in(f + 1);
+            load_dc(f + 2);                    // slot (f+2)%3 == (f-1)%3; zero-filled when f+2 >= T
+        }
+        __syncthreads();
+    }
+    // combine the ROWS threads that share a channel pair, then one partial row per workgroup
+    float* red = reinterpret_cast<float*>(smem);   // [2592]
+    for (int i = tid; i < 2592; i += P::NT) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        atomicAdd(&red[(2 * cp) * 27 + t], acc[t][0]);
+        atomicAdd(&red[(2 * cp + 1) * 27 + t], acc[t][1]);
+    }
+    __syncthreads();
+    float* prow = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2592;
+    for (int i = tid; i < 2592; i += P::NT) prow[i] = red[i];
+}
+
+template <typename TA, int S>
+static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
+                                   int T, int H, int W, int Ho, int Wo, hipStream_t st) {
+    using P = PoolTile<TA, S>;
+    constexpr int SM = P::IN_BYTES + 3 * P::NTOK * 96 * (int)sizeof(TA);
+    static_assert(SM >= 2592 * 4, "partial row must fit");
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_tiled_kernel<TA, S>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pool_wgrad_tiled_kernel<TA, S>), grid, dim3(P::NT), SM, st, (const TA*)qkv, ld, chan_off, (const TA*)dconv,
+                       part, heads, T, H, W, Ho, Wo);
+    MVIT_LAUNCH_CHECK();
+    return (int)(grid.x * grid.y);
+}
+
+// internal: returns the number of [2592]-float partial rows written, or a negative error (strides 1 and 2 only)
+int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
+                                   int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st) {
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    if (stride_hw == 1)
+        return act_dtype == MVIT_BF16 ? launch_pool_wgrad_tiled<bf16_t, 1>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st)
+                                      : launch_pool_wgrad_tiled<float, 1>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st);
+    return act_dtype == MVIT_BF16 ? launch_pool_wgrad_tiled<bf16_t, 2>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st)
+                                  : launch_pool_wgrad_tiled<float, 2>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st);
+}
+
 // internal (used by pool_bwd.hip): LN-backward of the pooled conv through the tiled march; returns the number of partial rows
 // written to part ([rows][96], d_gamma only) or a negative error.  Only strides 1 and 2.
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,

@@ -11,6 +11,8 @@
 
 extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_scale, int64_t rows_per_scale,
                            float* out, int accumulate, float* workspace, void* stream);
+int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
+                                   int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st);
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
                                     void* dconv, float* part, int B, int heads, int T, int H, int W, int stride_hw, float eps,
                                     int act_dtype, hipStream_t st);
@@ -314,7 +316,8 @@ extern "C" int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H
     if (stride_hw == 2) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
     if (rows < PB_MAXBLK) rows = PB_MAXBLK;
     (void)T;
-    return (rows * 192 + (int64_t)PW_MAXBLK * 2592) * (int64_t)sizeof(float);
+    const int64_t wrows = rows > PW_MAXBLK ? rows : PW_MAXBLK;    // tiled wgrad: one [2592] partial row per tile workgroup
+    return (rows * 192 + wrows * 2592) * (int64_t)sizeof(float);
 }
 
 // dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.
@@ -364,11 +367,19 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
     MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, st, (const TA*)qkv, ld, chan_off,         \
-                       (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                     \
-    MVIT_LAUNCH_CHECK();                                                                                                   \
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, (int)b3, 2592, dw, dw, 2592, 1);              \
-    MVIT_LAUNCH_CHECK();
+    if (tiled) {                                                                                                           \
+        const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
+                                                      act_dtype, st);                                                      \
+        if (wr < 0) return wr;                                                                                             \
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, wr, 2592, dw, dw, 2592, 1);               \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+    } else {                                                                                                               \
+        hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, st, (const TA*)qkv, ld, chan_off,     \
+                           (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                 \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, (int)b3, 2592, dw, dw, 2592, 1);          \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+    }
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN
     return MVIT_OK;
