@@ -188,6 +188,12 @@ int mvit_grad_norm(const void* chunk_table, int nchunks, float max_norm, float* 
 int mvit_adamw_step(const void* chunk_table, int nchunks, const float* norm_coef, float lr, float beta1, float beta2,
                     float eps, int step, void* stream);
 
+/* Sliding-window front end (scripts/module_wrapper.py:304-370,384-397; scripts/utils.py:172-211): gather frame_length frames
+ * per window by index from the decoded uint8 stream [N][H][W][3], resize to SxS with OpenCV's 8-bit INTER_LINEAR arithmetic
+ * (aspect ignored), /255, (x-mean)/std, write fp32 [nclips][3][frame_length][S][S]. frame_idx: device int32. */
+int mvit_window_preprocess(const void* frames, const int* frame_idx, float* out, int H, int W, int S, int nclips,
+                           int frame_length, float mean, float std, void* stream);
+
 /* fp32 -> bf16 (round to nearest even) conversion of parameters, n elements. */
 int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
