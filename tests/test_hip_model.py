@@ -89,3 +89,23 @@ def test_train_mode_returns_logits():
     out = model.train()([clip])
     assert out.requires_grad and out.shape == (meta["batch"], 18)
     assert not torch.allclose(out.sum(1), torch.ones(meta["batch"], device=out.device))   # raw logits, not softmax
+
+
+def test_32x3_variant_matches_oracle_on_this_host():
+    """SURVEY section 8f rank 4: the depth-24 32x3 config (T'=16, stages at blocks 2/5/21) runs on the same kernels;
+    checked against the oracle evaluated on this box's CPU (no fixture: weights/clip regenerated from seeds)."""
+    import os
+    from conftest import ROOT
+    from aicity_action_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_32x3_CONV.yaml"), ["NUM_GPUS", 1, "HIP.PRECISION", "fp32"])
+    mv = copy.deepcopy(cfg.MVIT.to_dict())
+    model = build_model(cfg).eval()
+    load_synth_weights(model, 4)
+    clip = synth_clip(1, 32, 224, 9)
+    with torch.no_grad():
+        probs, logits = model._forward_hip(clip.cuda(), return_logits=True)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o_probs, o_logits = O.forward(sd, clip, mv)
+    err = (logits.cpu() - o_logits).abs().max().item()
+    print("[32x3 fp32] logits err vs oracle %.2e" % err)
+    assert err <= FP32_LOGIT_TOL
