@@ -10,12 +10,14 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmvit_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "lib", "libmvit_hip_f16.so")   # same sources, 16-bit activation type = IEEE half
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL = 1, 2, 4
 
 _lib = None
+_lib_f16 = None
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -65,27 +67,36 @@ def build(force=False):
     """Compile every HIP source for gfx950 into lib/libmvit_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mvit_hip.h"))
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    if not force and all(os.path.exists(p) and all(os.path.getmtime(p) >= os.path.getmtime(s) for s in srcs)
+                         for p in (LIB_PATH, LIB_PATH_F16)):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     subprocess.check_call(["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))])
     return LIB_PATH
 
 
-def lib():
-    global _lib
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C aicity_action_amd/csrc`. There is no CPU fallback for the HIP path." % path)
+    L = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(half="bf16"):
+    """The kernel library; half selects what the 16-bit activation type (dtype code BF16) means: "bf16" or "fp16"."""
+    global _lib, _lib_f16
+    if half == "fp16":
+        if _lib_f16 is None:
+            _lib_f16 = _load(LIB_PATH_F16)
+        return _lib_f16
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "libmvit_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C aicity_action_amd/csrc`. There is no CPU fallback for the HIP path." % LIB_PATH)
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(L, name)  # AttributeError if the library does not export it
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
 
 

@@ -27,9 +27,9 @@ class _Ctx(object):
 
     def __init__(self, model):
         self.m = model
-        self.L = _hip.lib()
-        self.act = _hip.BF16 if model.precision == "bf16" else _hip.F32
-        self.adt = torch.bfloat16 if self.act == _hip.BF16 else torch.float32
+        self.L = model._lib()
+        self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
+        self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
 
     def w(self, p):
         return self.m._w(p, self.act)
@@ -42,7 +42,7 @@ class _Ctx(object):
         if ent is None or ent[0] != p._version or ent[1].device != p.device:
             t = p.detach().t().contiguous()
             if self.act == _hip.BF16:
-                buf = torch.empty(t.shape, dtype=torch.bfloat16, device=p.device)
+                buf = torch.empty(t.shape, dtype=self.adt, device=p.device)
                 _hip.check(self.L.mvit_cast_f32_to_bf16(_hip.ptr(t), _hip.ptr(buf), t.numel(), _st()), "cast")
                 t = buf
             ent = (p._version, t)
@@ -56,8 +56,8 @@ class _Ctx(object):
         y = torch.empty(M, N, dtype=out_dtype, device=a.device)
         epi = (_hip.EPI_BIAS if bias is not None else 0) | (_hip.EPI_GELU if gelu else 0) | (
             _hip.EPI_RESIDUAL if residual is not None else 0)
-        adt = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
-        odt = _hip.BF16 if out_dtype == torch.bfloat16 else _hip.F32
+        adt = _hip.F32 if a.dtype == torch.float32 else _hip.BF16
+        odt = _hip.F32 if out_dtype == torch.float32 else _hip.BF16
         _hip.check(self.L.mvit_linear_fwd(_hip.ptr(a), adt, K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(residual), N,
                                           _hip.ptr(row_scale), rps, _hip.ptr(y), odt, N, M, N, K, epi, self.act, _st()),
                    "linear %dx%dx%d" % (M, N, K))
@@ -67,8 +67,8 @@ class _Ctx(object):
         """(dW, db): weight gradient and the fused bias gradient (column sums of the scaled dy)."""
         dW = torch.zeros(N, K, dtype=torch.float32, device=a.device)
         db = torch.zeros(N, dtype=torch.float32, device=a.device)
-        adt = _hip.BF16 if a.dtype == torch.bfloat16 else _hip.F32
-        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        adt = _hip.F32 if a.dtype == torch.float32 else _hip.BF16
+        ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
                                             _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
         return dW, db
@@ -77,7 +77,7 @@ class _Ctx(object):
         M, N = dy.shape
         out = torch.empty(N, dtype=torch.float32, device=dy.device)
         ws = _ws(self.L.mvit_colsum_workspace_bytes(N), dy.device)
-        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         _hip.check(self.L.mvit_colsum(_hip.ptr(dy), ddt, M, N, _hip.ptr(row_scale), rps, _hip.ptr(out), 0, _hip.ptr(ws), _st()),
                    "colsum")
         return out
@@ -94,7 +94,7 @@ class _Ctx(object):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _ws(self.L.mvit_layernorm_bwd_workspace_bytes(C), x.device)
-        ddt = _hip.BF16 if dy.dtype == torch.bfloat16 else _hip.F32
+        ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         _hip.check(self.L.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
                                              _hip.ptr(dx), 1 if accumulate else 0, _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws),
                                              rows, C, norm.eps, _st()), "ln_bwd")

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + koff[ks]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                s[kb] = mfma16(kf, qf[ks], s[kb]);
             }
         }
         // ---- online softmax: raw-score running max, scale folded into the exp2 argument -----------------
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s16], o[db], 0, 0, 0);
+                o[db] = mfma16(vf, pf[s16], o[db]);
             }
         }
     }

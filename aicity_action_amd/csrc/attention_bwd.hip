@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             for (int ks = 0; ks < 6; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + koff[ks]);
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vr + koff[ks]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);      // S^T  = K . Q^T
-                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);   // dP^T = V . dO^T
+                s[kb] = mfma16(kf, qf[ks], s[kb]);      // S^T  = K . Q^T
+                dp[kb] = mfma16(vf, dof[ks], dp[kb]);   // dP^T = V . dO^T
             }
         }
         const int kbase = kt * B_T;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
             for (int db = 0; db < 3; ++db) {
                 const bf16x8 kf = tr_frag(sKp + t_lane + s16 * 16 * B_ROWB + db * 64);
-                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dsf[s16], dq[db], 0, 0, 0);
+                dq[db] = mfma16(kf, dsf[s16], dq[db]);
             }
     }
     if (q_ok) {
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             for (int ks = 0; ks < 6; ++ks) {
                 const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qr + roff[ks]);
                 const bf16x8 df = *reinterpret_cast<const bf16x8*>(dr + roff[ks]);
-                s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s[qb], 0, 0, 0);
-                dp[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp[qb], 0, 0, 0);
+                s[qb] = mfma16(qf, kf[ks], s[qb]);
+                dp[qb] = mfma16(df, vf[ks], dp[qb]);
             }
         }
         bf16x8 pf[4], dsf[4];
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             for (int db = 0; db < 3; ++db) {
                 const bf16x8 dof = tr_frag(sDp + t_lane + s16 * 16 * B_ROWB + db * 64);
                 const bf16x8 qtf = tr_frag(sQp + t_lane + s16 * 16 * B_ROWB + db * 64);
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf[s16], dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf[s16], dk[db], 0, 0, 0);
+                dv[db] = mfma16(dof, pf[s16], dv[db]);
+                dk[db] = mfma16(qtf, dsf[s16], dk[db]);
             }
     }
     if (SPLIT) {

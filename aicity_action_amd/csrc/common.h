@@ -5,7 +5,11 @@
 
 #include "../../include/mvit_hip.h"
 
-typedef uint16_t bf16_t;  // raw bf16 bits
+// The 16-bit activation type.  One source tree builds two libraries: libmvit_hip.so (bfloat16, the default) and, with
+// -DMVIT_HALF_IS_FP16, libmvit_hip_f16.so in which every "bf16" below means IEEE half (same MFMA rate on gfx950, 3 more
+// mantissa bits -> closes the 1e-3 logit gate that bf16 storage cannot).  All bit-level conversions go through the
+// helpers of this header; `bf16_t` stays the name of the raw 16-bit storage type in both builds.
+typedef uint16_t bf16_t;  // raw 16-bit storage (bf16, or fp16 under MVIT_HALF_IS_FP16)
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;    // MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
@@ -17,6 +21,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
         if (hipGetLastError() != hipSuccess) return MVIT_ELAUNCH; \
     } while (0)
 
+#ifdef MVIT_HALF_IS_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma16_t;
+#define MVIT_ONE16 ((short)0x3C00)
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {     // round-to-nearest-even (v_cvt_f16_f32)
+    _Float16 h = (_Float16)f;
+    bf16_t r;
+    __builtin_memcpy(&r, &h, 2);
+    return r;
+}
+__device__ __forceinline__ float lo16_to_f32(uint32_t u) { return bf16_to_f32((bf16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float hi16_to_f32(uint32_t u) { return bf16_to_f32((bf16_t)(u >> 16)); }
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma16_t;
+#define MVIT_ONE16 ((short)0x3F80)
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
@@ -26,6 +49,9 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return *reinterpret_cast<bf16_t*>(&b);
 }
+__device__ __forceinline__ float lo16_to_f32(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16_to_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
@@ -46,19 +72,19 @@ __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_ca
 __device__ __forceinline__ float4 load4(const bf16_t* p) {
     uint2 u = *reinterpret_cast<const uint2*>(p);
     float4 r;
-    r.x = __uint_as_float(u.x << 16);
-    r.y = __uint_as_float(u.x & 0xffff0000u);
-    r.z = __uint_as_float(u.y << 16);
-    r.w = __uint_as_float(u.y & 0xffff0000u);
+    r.x = lo16_to_f32(u.x);
+    r.y = hi16_to_f32(u.x);
+    r.z = lo16_to_f32(u.y);
+    r.w = hi16_to_f32(u.y);
     return r;
 }
 // 8 consecutive bf16 (one 16-byte load) -> two float4
 __device__ __forceinline__ void load8(const bf16_t* p, float4& lo, float4& hi) {
     const uint4 u = *reinterpret_cast<const uint4*>(p);
-    lo.x = __uint_as_float(u.x << 16); lo.y = __uint_as_float(u.x & 0xffff0000u);
-    lo.z = __uint_as_float(u.y << 16); lo.w = __uint_as_float(u.y & 0xffff0000u);
-    hi.x = __uint_as_float(u.z << 16); hi.y = __uint_as_float(u.z & 0xffff0000u);
-    hi.z = __uint_as_float(u.w << 16); hi.w = __uint_as_float(u.w & 0xffff0000u);
+    lo.x = lo16_to_f32(u.x); lo.y = hi16_to_f32(u.x);
+    lo.z = lo16_to_f32(u.y); lo.w = hi16_to_f32(u.y);
+    hi.x = lo16_to_f32(u.z); hi.y = hi16_to_f32(u.z);
+    hi.z = lo16_to_f32(u.w); hi.w = hi16_to_f32(u.w);
 }
 __device__ __forceinline__ void load8(const float* p, float4& lo, float4& hi) {
     lo = *reinterpret_cast<const float4*>(p);
@@ -74,6 +100,15 @@ __device__ __forceinline__ void store4(bf16_t* p, float4 v) {
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// D = A(32x16) * B(16x32) + C on 16-bit operands held as raw bits (bf16x8 = 8 shorts); fp32 accumulate
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef MVIT_HALF_IS_FP16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma16_t, a), __builtin_bit_cast(mfma16_t, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma16_t, a), __builtin_bit_cast(mfma16_t, b), c, 0, 0, 0);
+#endif
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

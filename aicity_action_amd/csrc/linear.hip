@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(
                 const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(fb + nb * 32 * L_ROWB + foff[ks]);
 #pragma unroll
                 for (int mb = 0; mb < WM; ++mb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = mfma16(af[mb], bfr, acc[mb][nb]);
             }
         }
     }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void linear_dma_kernel(
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
                 const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(base + fb_off + nb * 32 * D_ROWB + foff[ks]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[nb], 0, 0, 0);
+                acc[nb] = mfma16(af, bfr, acc[nb]);
             }
         }
     }
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
             for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = mfma16(wf[nb], xf[mb], acc[mb][nb]);
         }
     }
 

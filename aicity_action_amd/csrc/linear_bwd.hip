@@ -61,7 +61,7 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
         for (int i = 0; i < 16; ++i) acc[kb][i] = 0.f;
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+    for (int e = 0; e < 8; ++e) ones[e] = MVIT_ONE16;
 
     // staging: 64 rows x 12 chunks = 768 chunks per slab, 4 per thread
     int s_off[4];
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
                 bf16x8 af;
                 af[0] = alo[0]; af[1] = alo[1]; af[2] = alo[2]; af[3] = alo[3];
                 af[4] = ahi[0]; af[5] = ahi[1]; af[6] = ahi[2]; af[7] = ahi[3];
-                acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, af, acc[kb], 0, 0, 0);
+                acc[kb] = mfma16(df, af, acc[kb]);
             }
-            if (do_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, ones, bacc, 0, 0, 0);   // dy^T . 1 = bias gradient
+            if (do_bias) bacc = mfma16(df, ones, bacc);   // dy^T . 1 = bias gradient
         }
     }
     // acc[kb][i]: row n = 32*wave + (i&3) + 8(i>>2) + 4h, col k = 32kb + r  -> 128 contiguous bytes per half-wave atomic

@@ -139,8 +139,8 @@ __device__ __forceinline__ void load2(const TA* p, float& a, float& b);
 template <>
 __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float& a, float& b) {
     const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
-    a = __uint_as_float(u << 16);
-    b = __uint_as_float(u & 0xffff0000u);
+    a = lo16_to_f32(u);
+    b = hi16_to_f32(u);
 }
 template <>
 __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) {

@@ -285,7 +285,11 @@ extern "C" int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, voi
     return MVIT_OK;
 }
 
-extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1"; }
+#ifdef MVIT_HALF_IS_FP16
+extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: fp16)"; }
+#else
+extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: bf16)"; }
+#endif
 
 extern "C" const char* mvit_strerror(int code) {
     switch (code) {

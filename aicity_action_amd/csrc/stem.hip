@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
                     const uint2 lo = *reinterpret_cast<const uint2*>(ap);
                     const uint2 hi = *reinterpret_cast<const uint2*>(ap + 8);
                     uint4 u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), bfrag[s], acc[mb], 0, 0, 0);
+                    acc[mb] = mfma16(*reinterpret_cast<bf16x8*>(&u), bfrag[s], acc[mb]);
                 }
             }
             // epilogue: + bias + pos_spatial[hw] + pos_temporal[t], token-major fp32

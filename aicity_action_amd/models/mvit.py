@@ -171,20 +171,26 @@ class MViT(nn.Module):
     def precision(self):
         hip = getattr(self.cfg, "HIP", None)
         p = getattr(hip, "PRECISION", "bf16") if hip is not None else "bf16"
-        if p not in ("bf16", "fp32"):
-            raise ValueError("cfg.HIP.PRECISION must be 'bf16' or 'fp32', got %r" % (p,))
+        if p not in ("bf16", "fp16", "fp32"):
+            raise ValueError("cfg.HIP.PRECISION must be 'bf16', 'fp16' or 'fp32', got %r" % (p,))
         return p
+
+    def _lib(self):
+        return _hip.lib("fp16" if self.precision == "fp16" else "bf16")
+
+    def _half_dtype(self):
+        return torch.float16 if self.precision == "fp16" else torch.bfloat16
 
     def _w(self, param, act):
         """Weight in the activation dtype of the MFMA path (fp32 master -> cached bf16 copy)."""
         if act == _hip.F32:
             return param
-        key = id(param)
+        key = (self.precision, id(param))
         ent = self._bf16_cache.get(key)
         if ent is None or ent[0] != param._version or ent[1].device != param.device:
-            buf = torch.empty(param.shape, dtype=torch.bfloat16, device=param.device)
+            buf = torch.empty(param.shape, dtype=self._half_dtype(), device=param.device)
             st = torch.cuda.current_stream().cuda_stream
-            _hip.check(_hip.lib().mvit_cast_f32_to_bf16(_hip.ptr(param), _hip.ptr(buf), param.numel(), st), "cast")
+            _hip.check(self._lib().mvit_cast_f32_to_bf16(_hip.ptr(param), _hip.ptr(buf), param.numel(), st), "cast")
             ent = (param._version, buf)
             self._bf16_cache[key] = ent
         return ent[1]
@@ -196,6 +202,9 @@ class MViT(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("MViT (HIP path) needs its input on a gfx950 device; there is no CPU fallback")
         if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            if self.precision == "fp16":
+                raise NotImplementedError("HIP.PRECISION fp16 is inference-only (no loss scaling in the training path); "
+                                          "train with bf16 or fp32")
             # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
             return forward_with_grad(self, x, return_logits)
@@ -203,11 +212,11 @@ class MViT(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _forward_hip(self, clip, return_logits=False, taps=None):
-        L = _hip.lib()
+        L = self._lib()
         dev = clip.device
         st = torch.cuda.current_stream().cuda_stream
-        act = _hip.BF16 if self.precision == "bf16" else _hip.F32
-        adt = torch.bfloat16 if act == _hip.BF16 else torch.float32
+        act = _hip.F32 if self.precision == "fp32" else _hip.BF16     # BF16 = "the 16-bit type" of the loaded library
+        adt = torch.float32 if act == _hip.F32 else self._half_dtype()
         clip = clip.contiguous().float()
         B, Cin, T, S, S2 = clip.shape
         assert Cin == 3 and S == S2 and [T, S, S] == self.input_dims, "clip shape %s != configured %s" % (
@@ -247,7 +256,7 @@ class MViT(nn.Module):
         y = torch.empty(M, N, dtype=out_dtype, device=a.device)
         epi = (_hip.EPI_BIAS if bias is not None else 0) | (_hip.EPI_GELU if gelu else 0) | (
             _hip.EPI_RESIDUAL if residual is not None else 0)
-        odt = _hip.BF16 if out_dtype == torch.bfloat16 else _hip.F32
+        odt = _hip.F32 if out_dtype == torch.float32 else _hip.BF16
         _hip.check(L.mvit_linear_fwd(_hip.ptr(a), a_dt, K, _hip.ptr(self._w(weight, act)), _hip.ptr(bias),
                                      _hip.ptr(residual), N, None, 0, _hip.ptr(y), odt, N, M, N, K, epi, act, st),
                    "linear %dx%dx%d" % (M, N, K))

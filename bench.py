@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "window"])
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -143,12 +143,12 @@ def main():
     roofline = None
     extra_rooflines = {}
     if rank == 0 and not args.no_kernel_timing and args.mode != "window":
-        L = _hip.lib()
-        act = _hip.BF16 if args.precision == "bf16" else _hip.F32
-        adt = torch.bfloat16 if act == _hip.BF16 else torch.float32
+        L = core._lib()
+        act = _hip.F32 if args.precision == "fp32" else _hip.BF16
+        adt = torch.float32 if act == _hip.F32 else core._half_dtype()
         st = torch.cuda.current_stream().cuda_stream
         flops = attention_flops(core.geoms, args.batch)
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
         reps = 5
 
         def timed(fn):
@@ -190,7 +190,7 @@ def main():
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
-        sfx = "bf16" if act else "f32"
+        sfx = args.precision if act else "f32"
         fwd_rl = rl("attn_fwd_%s_kernel" % sfx, sum(flops), fwd_ms, per_f)
         if train:
             roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b)
@@ -249,7 +249,7 @@ def main():
 
     if rank == 0:
         gf = GFLOP_PER_CLIP[args.crop] * (3.0 if train else 1.0)   # train step = 3x forward FLOPs
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS   # fp16 MFMA rate = bf16 rate on gfx950
         line = {
             "metric": "clips/sec (node) MViTv2-B 16x4@%d %s" % (args.crop, args.mode),
             "value": round(clips_per_s, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
