@@ -591,6 +591,205 @@ static int launch_linear_big(const void* a, int64_t lda, const void* w, const fl
     return MVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the 128x192 kernel.  Each workgroup walks a strided list of tiles inside its XCD's
+// contiguous tile range and treats (tile, slab) as ONE stream: while the last slab of a tile is multiplied the
+// first slab of the next tile is already in flight, so the output stores of a tile overlap the next tile's
+// load latency instead of ending the workgroup.  The bias is the accumulator's initial value (scalar loads at
+// tile start), which leaves the common epilogues (bias, bias+GELU) free of vector loads: the stores trail and the
+// next slab wait uses vmcnt(#stores) instead of vmcnt(0).
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256, 2) void linear_pers_kernel(
+    const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
+    TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NST = sizeof(TO) == 4 ? 24 : 12;     // vector stores per wave per full tile
+
+    const int ntn = N / G_BN;
+    const int nt = (int)((M + G_BM - 1) / G_BM) * ntn;
+    const int per = gridDim.x >> 3;                     // workgroups per XCD (grid is a multiple of 8)
+    const int q = (nt + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int t_end = min(nt, (xcd + 1) * q);
+    int t = xcd * q + (blockIdx.x >> 3);
+    if (t >= t_end) return;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // DMA piece p (1 KiB = 8 rows x 128 B): lane -> row 8p + lane/8, position lane%8, logical chunk pos ^ swz(row)
+    int a_row[4], a_chunk[4], b_off[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_row[i] = 8 * (4 * wave + i) + (lane >> 3);
+        a_chunk[i] = 8 * ((lane & 7) ^ ((a_row[i] >> 1) & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = 8 * (6 * wave + i) + (lane >> 3);
+        b_off[i] = row * K + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+    }
+    int foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
+    const int fx_off = (64 * wm + r) * G_ROWB;                 // token rows  (MFMA B operand)
+    const int fw_off = G_PANEL_A + (96 * wn + r) * G_ROWB;     // weight rows (MFMA A operand)
+    const int nk = K / G_BK;
+
+    // per-tile DMA sources
+    const bf16_t* a_src[4];
+    const bf16_t* w_src;
+    auto setup = [&](int tile) {
+        const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t m = m0 + a_row[i];
+            m = m < M ? m : M - 1;
+            a_src[i] = a + m * lda + a_chunk[i];
+        }
+        w_src = w + (int64_t)(tile % ntn) * G_BN * K;
+    };
+    auto dma = [&](int k0, int buf) {
+        char* base = smem + buf * G_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + k0), (lptr_t*)(base + 1024 * (4 * wave + i)), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(w_src + b_off[i] + k0),
+                                             (lptr_t*)(base + G_PANEL_A + 1024 * (6 * wave + i)), 16, 0, 0);
+    };
+
+    setup(t);
+    dma(0, 0);
+    int s = 0;                  // running slab counter: slab s lives in buffer s & 1
+    bool trail = false;         // the previous tile left exactly NST stores behind the slab-0 DMA
+    for (;;) {
+        const int tn = t % ntn;
+        const int64_t m0 = (int64_t)(t / ntn) * G_BM;
+        const int n0 = tn * G_BN;
+        const bool full_m = m0 + G_BM <= M;
+        const int t_next = t + per;
+        const bool has_next = t_next < t_end;
+
+        // acc[mb][nb]: rows (registers) = n = 96*wn + 32*nb + (i&3) + 8*(i>>2) + 4*h ; column (lane) = m = 64*wm + 32*mb + r
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const float* bp = bias + n0 + 96 * wn + 32 * nb;      // wave-uniform -> scalar loads
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float b = 0.f;
+                if (epilogue & MVIT_EPI_BIAS) {
+                    const int c = (i & 3) + 8 * (i >> 2);
+                    const float lo = bp[c], hi = bp[c + 4];
+                    b = h ? hi : lo;
+                }
+                acc[0][nb][i] = b;
+                acc[1][nb][i] = b;
+            }
+        }
+
+        for (int kt = 0; kt < nk; ++kt, ++s) {
+            if (kt == 0 && trail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab s have landed
+            __builtin_amdgcn_s_barrier();                          // everyone's have; the other buffer is free
+            if (kt + 1 < nk) dma((kt + 1) * G_BK, (s + 1) & 1);
+            else if (has_next) { setup(t_next); dma(0, (s + 1) & 1); }
+            const char* base = smem + (s & 1) * G_BUF;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 xf[2], wf[3];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(base + fx_off + mb * 32 * G_ROWB + foff[ks]);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(base + fw_off + nb * 32 * G_ROWB + foff[ks]);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[mb][nb] = mfma16(wf[nb], xf[mb], acc[mb][nb]);
+            }
+        }
+
+        // ---- epilogue from registers: lane = output row, quads of 4 consecutive columns ------------------
+        const bool loads_in_epilogue = row_scale || (epilogue & MVIT_EPI_RESIDUAL);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int64_t m = m0 + 64 * wm + 32 * mb + r;
+            const bool ok = full_m || m < M;
+            const float sc = (row_scale && ok) ? row_scale[m / rows_per_scale] : 1.f;
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                const int nbase = n0 + 96 * wn + 32 * nb + 4 * h;    // + 8*q
+                float4 v[4];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    v[qd] = make_float4(acc[mb][nb][4 * qd], acc[mb][nb][4 * qd + 1], acc[mb][nb][4 * qd + 2], acc[mb][nb][4 * qd + 3]);
+                    if (epilogue & MVIT_EPI_GELU) {
+                        v[qd].x = gelu_fast(v[qd].x); v[qd].y = gelu_fast(v[qd].y);
+                        v[qd].z = gelu_fast(v[qd].z); v[qd].w = gelu_fast(v[qd].w);
+                    }
+                    if (row_scale) { v[qd].x *= sc; v[qd].y *= sc; v[qd].z *= sc; v[qd].w *= sc; }
+                }
+                if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        if (ok) {
+                            if (epilogue & MVIT_EPI_RESIDUAL) {
+                                const float4 rr = load4(residual + m * ldr + nbase + 8 * qd);
+                                v[qd].x += rr.x; v[qd].y += rr.y; v[qd].z += rr.z; v[qd].w += rr.w;
+                            }
+                            *reinterpret_cast<float4*>(y + m * ldy + nbase + 8 * qd) = v[qd];
+                        }
+                    }
+                } else {
+                    // 16-bit out (no residual): pair the quads of the two half-waves with permlane32_swap -> 16-B pieces
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd += 2) {
+                        uint32_t a0 = pack_bf16x2(v[qd].x, v[qd].y), a1 = pack_bf16x2(v[qd].z, v[qd].w);
+                        uint32_t b0 = pack_bf16x2(v[qd + 1].x, v[qd + 1].y), b1 = pack_bf16x2(v[qd + 1].z, v[qd + 1].w);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (ok) *reinterpret_cast<uint4*>(y + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (qd + h)) = o;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        // stores trail behind the already-issued slab-0 DMA only when nothing in the epilogue had to wait on a load
+        trail = full_m && !loads_in_epilogue;
+        if (!trail) { /* epilogue loads already forced the DMA to land; stores may still be in flight */ }
+        t = t_next;
+    }
+}
+
+template <typename TO>
+static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+                              int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                              int K, int epi, hipStream_t st) {
+    const int64_t nt = ((M + G_BM - 1) / G_BM) * (N / G_BN);
+    if (nt > 0x7fffffff) return MVIT_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    const int64_t q = (nt + 7) / 8;
+    const int per = (int)(q < 64 ? q : 64);             // 2 workgroups per CU x 32 CUs per XCD
+    hipLaunchKernelGGL((linear_pers_kernel<TO>), dim3((unsigned)(8 * per)), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+                       (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 template <typename TA, typename TO>
 static int launch_linear_mfma(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
                               int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
@@ -711,6 +910,11 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
     static const bool use_big = getenv("MVIT_GEMM_NO_BIG") == nullptr;
     if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && K % G_BK == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
         !(out_dtype == MVIT_BF16 && (epilogue & MVIT_EPI_RESIDUAL))) {
+        static const bool use_pers = getenv("MVIT_GEMM_NO_PERS") == nullptr;
+        if (use_pers && out_dtype == MVIT_BF16)
+            return launch_linear_pers<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+        if (use_pers && out_dtype == MVIT_F32)
+            return launch_linear_pers<float>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
         if (out_dtype == MVIT_BF16)
             return launch_linear_big<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
         if (out_dtype == MVIT_F32)

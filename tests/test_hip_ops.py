@@ -96,6 +96,35 @@ def test_linear_bf16_with_fp32_a_and_row_scale(hip_lib):
     _close(y, ref, 2e-3)
 
 
+@pytest.mark.parametrize("epi", ["b", "bg", "br", "brs"])
+def test_linear_persistent_many_tiles(hip_lib, epi):
+    """More tiles than resident workgroups (persistent 128x192 kernel: cross-tile prefetch, trailing stores), ragged M."""
+    M, N, K = 128 * 300 + 40, 576, 192
+    a = _rnd(M, K, seed=21).to(torch.bfloat16)
+    w = _rnd(N, K, seed=22, scale=0.05).to(torch.bfloat16)
+    bias = _rnd(N, seed=23, scale=0.1)
+    res = _rnd(M, N, seed=24)
+    rps = 1000
+    scale = torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(3)) * 2
+    ad, wd, bd, rd, sd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), scale.to(DEV)
+    ref = ad.float() @ wd.float().t() + bd
+    flags = _hip.EPI_BIAS
+    if "g" in epi:
+        ref = F.gelu(ref)
+        flags |= _hip.EPI_GELU
+    if "s" in epi:
+        ref = ref * sd.repeat_interleave(rps)[:M, None]
+    if "r" in epi:
+        ref = ref + rd
+        flags |= _hip.EPI_RESIDUAL
+    for out_bf16 in ([False] if "r" in epi else [False, True]):
+        y = torch.empty(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=DEV)
+        _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(ad), _hip.BF16, K, _hip.ptr(wd), _hip.ptr(bd),
+                                           _hip.ptr(rd) if "r" in epi else None, N, _hip.ptr(sd) if "s" in epi else None, rps,
+                                           _hip.ptr(y), _hip.BF16 if out_bf16 else _hip.F32, N, M, N, K, flags, _hip.BF16, _st()))
+        _close(y, ref.cpu(), 1e-2 if out_bf16 else 2e-3)
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
