@@ -910,7 +910,10 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
     static const bool use_big = getenv("MVIT_GEMM_NO_BIG") == nullptr;
     if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && K % G_BK == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
         !(out_dtype == MVIT_BF16 && (epilogue & MVIT_EPI_RESIDUAL))) {
-        static const bool use_pers = getenv("MVIT_GEMM_NO_PERS") == nullptr;
+        // persistent form only where the epilogue has no vector loads (measured: with residual / drop-path loads the
+        // one-tile-per-workgroup form overlaps them better)
+        static const bool pers_env = getenv("MVIT_GEMM_NO_PERS") == nullptr;
+        const bool use_pers = pers_env && !row_scale && !(epilogue & MVIT_EPI_RESIDUAL);
         if (use_pers && out_dtype == MVIT_BF16)
             return launch_linear_pers<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
         if (use_pers && out_dtype == MVIT_F32)
