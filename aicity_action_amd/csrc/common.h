@@ -53,8 +53,17 @@ __device__ __forceinline__ float lo16_to_f32(uint32_t u) { return __uint_as_floa
 __device__ __forceinline__ float hi16_to_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 #endif
 
+// two fp32 -> one dword of two 16-bit values (lo in bits 0-15): a single v_cvt_pk_* instruction
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+#ifdef MVIT_HALF_IS_FP16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h16x2_v;
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 h16x2_v;
+#endif
+    const f32x2_v f = {lo, hi};
+    const h16x2_v v = __builtin_convertvector(f, h16x2_v);
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct ActIO;
