@@ -14,6 +14,7 @@
 #define A_QB 128          // queries per workgroup
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ int kslab_off(int row, int chunk) {
     int p = chunk + ((row >> 2) & 3);
@@ -48,25 +49,40 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
 
-    // staging map: chunk c = tid + 256*i of a [64][12-chunk] tile
-    int s_row[3], s_chk[3];
+    // staging map: a 64-key tile is one contiguous 12 KiB block of K (and of V); thread tid moves the 16-byte chunks
+    // c = tid + 256*i.  Global side: uniform tile base (scalar) + a constant 32-bit per-thread offset, so the loop
+    // spends no vector instructions on addresses.
+    int s_koff[3], s_voff[3];
+    uint32_t g_off[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = tid + 256 * i;
-        s_row[i] = c / 12;
-        s_chk[i] = c - s_row[i] * 12;
+        const int row = c / 12, chk = c - row * 12;
+        s_koff[i] = kslab_off(row, chk);
+        s_voff[i] = c * 16;
+        g_off[i] = (uint32_t)c * 16u;
     }
     uint4 rk[3], rv[3];
     auto gload = [&](int k0) {
+        const char* kt_base = reinterpret_cast<const char*>(Kb) + (int64_t)k0 * A_ROWB;   // wave-uniform
+        const char* vt_base = reinterpret_cast<const char*>(Vb) + (int64_t)k0 * A_ROWB;
+        if (k0 + A_KT <= Lk) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int key = k0 + s_row[i];
-            if (key < Lk) {
-                rk[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * 96 + 8 * s_chk[i]);
-                rv[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * 96 + 8 * s_chk[i]);
-            } else {
-                rk[i] = make_uint4(0, 0, 0, 0);
-                rv[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 3; ++i) {
+                rk[i] = *reinterpret_cast<const uint4*>(kt_base + g_off[i]);
+                rv[i] = *reinterpret_cast<const uint4*>(vt_base + g_off[i]);
+            }
+        } else {
+            const uint32_t lim = (uint32_t)(Lk - k0) * A_ROWB;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (g_off[i] < lim) {
+                    rk[i] = *reinterpret_cast<const uint4*>(kt_base + g_off[i]);
+                    rv[i] = *reinterpret_cast<const uint4*>(vt_base + g_off[i]);
+                } else {
+                    rk[i] = make_uint4(0, 0, 0, 0);
+                    rv[i] = make_uint4(0, 0, 0, 0);
+                }
             }
         }
     };
@@ -95,8 +111,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<uint4*>(sK + kslab_off(s_row[i], s_chk[i])) = rk[i];
-            *reinterpret_cast<uint4*>(sV + s_row[i] * A_ROWB + s_chk[i] * 16) = rv[i];
+            *reinterpret_cast<uint4*>(sK + s_koff[i]) = rk[i];
+            *reinterpret_cast<uint4*>(sV + s_voff[i]) = rv[i];
         }
         __syncthreads();
         if (kt + 1 < nkt) gload((kt + 1) * A_KT);
@@ -104,13 +120,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
         // ---- S^T = K . Q^T  (two 32-key blocks) ------------------------------------------------
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-            const char* kr = sK + (32 * kb + r) * A_ROWB;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + koff[ks]);
+        for (int ks = 0; ks < 6; ++ks) {       // the two key blocks alternate: no back-to-back dependent MFMAs
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * A_ROWB + koff[ks]);
                 s[kb] = mfma16(kf, qf[ks], s[kb]);
             }
         }
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
         }
         float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);      // v_max3_f32
         {   // both halves of the wave hold the same 32 queries (different keys): exchange maxima
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -142,8 +159,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
             m_run = m_new;
         }
-        const float mc = m_run * scale_log2e;
-        float psum = 0.f;
+        const f32x2 c2 = {scale_log2e, scale_log2e};
+        const float mcs = -m_run * scale_log2e;
+        const f32x2 mc2 = {mcs, mcs};
+        f32x2 ps2 = {0.f, 0.f};
         bf16x8 pf[4];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -152,14 +171,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                 uint32_t pk[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * sh + 2 * jj], scale_log2e, -mc));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * sh + 2 * jj + 1], scale_log2e, -mc));
-                    psum += p0 + p1;
-                    pk[jj] = pack_bf16x2(p0, p1);
+                    const f32x2 sv = {s[kb][8 * sh + 2 * jj], s[kb][8 * sh + 2 * jj + 1]};
+                    const f32x2 t = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
+                    const f32x2 pp = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    ps2 += pp;                                                          // v_pk_add_f32
+                    pk[jj] = pack_bf16x2(pp[0], pp[1]);
                 }
                 uint4 u = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 pf[2 * kb + sh] = *reinterpret_cast<bf16x8*>(&u);
             }
+        const float psum = ps2[0] + ps2[1];
         l_run += psum;
         // ---- O^T += V^T . P^T -------------------------------------------------------------------
 #pragma unroll
