@@ -15,6 +15,10 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((address_space(1))) const void a_gptr_t;
+typedef __attribute__((address_space(3))) void a_lptr_t;
+#define A_STAGES 3        // K/V tile ring (LDS-DMA, two tiles in flight)
+#define A_TILEB (2 * A_KT * A_ROWB)   // K image + V image of one tile = 24 KiB
 
 __device__ __forceinline__ int kslab_off(int row, int chunk) {
     int p = chunk + ((row >> 2) & 3);
@@ -22,18 +26,26 @@ __device__ __forceinline__ int kslab_off(int row, int chunk) {
     return row * A_ROWB + p * 16;
 }
 
+// Transposed LDS read issued as inline asm: through the builtin the compiler cannot tell the read apart from the
+// in-flight LDS-DMA writes of later tiles and puts s_waitcnt vmcnt(0) in front of it, which serialises the K/V ring.
+// The caller waits with lds_tr_wait() (operands tie the registers to the wait) before the first use.
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr16(uint32_t addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 template <bool ADD_Q>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                             const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                             float* __restrict__ LSE, int heads, int Lq, int Lk,
                                                             float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_KT * A_ROWB];
-    char* sK = smem;
-    char* sV = smem + A_KT * A_ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A_STAGES x (K image 12 KiB | V image 12 KiB)
 
     const int bh = blockIdx.y;            // b*heads + g
     const int b = bh / heads, g = bh - b * heads;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * A_QB + wave * A_QW;
 
@@ -49,40 +61,41 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
 
-    // staging map: a 64-key tile is one contiguous 12 KiB block of K (and of V); thread tid moves the 16-byte chunks
-    // c = tid + 256*i.  Global side: uniform tile base (scalar) + a constant 32-bit per-thread offset, so the loop
-    // spends no vector instructions on addresses.
-    int s_koff[3], s_voff[3];
-    uint32_t g_off[3];
+    // K/V tiles go global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 B land linearly at a wave-uniform LDS
+    // base), three K and three V pieces of 1 KiB per wave and tile.  A tile is one contiguous 12 KiB block of K (and V);
+    // LDS position p = 64*piece + lane of the K image holds chunk (p%12 - rot(row)) of row p/12, so the rotation swizzle
+    // is applied to the SOURCE address; the V image is linear.  Nothing is staged in registers.
+    uint32_t gk_off[3], gv_off[3];
+    int p_row[3], p_kc[3], p_vc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c / 12, chk = c - row * 12;
-        s_koff[i] = kslab_off(row, chk);
-        s_voff[i] = c * 16;
-        g_off[i] = (uint32_t)c * 16u;
+        const int p = 64 * (3 * wave + i) + lane;
+        const int row = p / 12, pos = p - row * 12;
+        int c = pos - ((row >> 2) & 3);
+        c = c < 0 ? c + 12 : c;
+        p_row[i] = row; p_kc[i] = c; p_vc[i] = pos;
+        gk_off[i] = (uint32_t)(row * 12 + c) * 16u;
+        gv_off[i] = (uint32_t)p * 16u;
     }
-    uint4 rk[3], rv[3];
-    auto gload = [&](int k0) {
+    auto dma = [&](int k0, int stage) {
         const char* kt_base = reinterpret_cast<const char*>(Kb) + (int64_t)k0 * A_ROWB;   // wave-uniform
         const char* vt_base = reinterpret_cast<const char*>(Vb) + (int64_t)k0 * A_ROWB;
+        char* dst = smem + stage * A_TILEB + 1024 * (3 * wave);
         if (k0 + A_KT <= Lk) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                rk[i] = *reinterpret_cast<const uint4*>(kt_base + g_off[i]);
-                rv[i] = *reinterpret_cast<const uint4*>(vt_base + g_off[i]);
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(kt_base + gk_off[i]), (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(vt_base + gv_off[i]), (a_lptr_t*)(dst + A_KT * A_ROWB + 1024 * i), 16, 0, 0);
             }
-        } else {
-            const uint32_t lim = (uint32_t)(Lk - k0) * A_ROWB;
+        } else {        // tail tile: rows past Lk re-read the last valid row (finite data; their scores are masked to -inf)
+            const int last = Lk - 1 - k0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                if (g_off[i] < lim) {
-                    rk[i] = *reinterpret_cast<const uint4*>(kt_base + g_off[i]);
-                    rv[i] = *reinterpret_cast<const uint4*>(vt_base + g_off[i]);
-                } else {
-                    rk[i] = make_uint4(0, 0, 0, 0);
-                    rv[i] = make_uint4(0, 0, 0, 0);
-                }
+                const int row = p_row[i] < last ? p_row[i] : last;
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(kt_base + (uint32_t)(row * 12 + p_kc[i]) * 16u),
+                                                 (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(vt_base + (uint32_t)(row * 12 + p_vc[i]) * 16u),
+                                                 (a_lptr_t*)(dst + A_KT * A_ROWB + 1024 * i), 16, 0, 0);
             }
         }
     };
@@ -106,16 +119,32 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = (Lk + A_KT - 1) / A_KT;
-    gload(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+    dma(0, 0);
+    if (nkt > 1) dma(A_KT, 1);
+    // consume the Q fragments once here: the vmcnt wait for them is paid before the loop, so inside it only the counted
+    // waits below touch vmcnt (the K/V DMAs stay in flight under the MFMAs)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<uint4*>(sK + s_koff[i]) = rk[i];
-            *reinterpret_cast<uint4*>(sV + s_voff[i]) = rv[i];
-        }
-        __syncthreads();
-        if (kt + 1 < nkt) gload((kt + 1) * A_KT);
+    for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]));
+    int stage = 0;
+#ifdef ATT_STAMP
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t tp = __builtin_readcyclecounter();
+    const uint64_t t_begin = tp, w_begin = wall_clock64();
+#define STAMP(i) { const uint64_t now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tp; tp = now_; }
+#else
+#define STAMP(i)
+#endif
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed once at most the 6 pieces of tile kt+1 are still outstanding (VMEM returns in order)
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(0)
+        __builtin_amdgcn_s_barrier();       // everyone's pieces landed; everyone is done with the stage refilled below
+        if (kt + 2 < nkt) dma((kt + 2) * A_KT, stage == 0 ? 2 : stage - 1);
+        const char* sK = smem + stage * A_TILEB;
+        const char* sV = sK + A_KT * A_ROWB;
+        stage = stage == A_STAGES - 1 ? 0 : stage + 1;
+        STAMP(1)
 
         // ---- S^T = K . Q^T  (two 32-key blocks) ------------------------------------------------
         f32x16 s[2];
@@ -123,13 +152,27 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+        {   // all 12 K fragments are requested before the first MFMA (counted lgkmcnt waits): LDS latency is paid once
+            bf16x8 kf[6][2];
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) {       // the two key blocks alternate: no back-to-back dependent MFMAs
+            for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * A_ROWB + koff[ks]);
-                s[kb] = mfma16(kf, qf[ks], s[kb]);
-            }
+                for (int kb = 0; kb < 2; ++kb)
+                    kf[ks][kb] = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * A_ROWB + koff[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks)       // the two key blocks alternate: no back-to-back dependent MFMAs
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) s[kb] = mfma16(kf[ks][kb], qf[ks], s[kb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // V^T fragments of the whole tile: requested now, they land under the softmax arithmetic
+        bf16x4 vlo[12], vhi[12];
+        {
+            const uint32_t va = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(sV) + v_lane_off;
+#define VTR(S16, DB) vlo[3 * S16 + DB] = lds_tr16<S16 * 16 * A_ROWB + DB * 64>(va); vhi[3 * S16 + DB] = lds_tr16<S16 * 16 * A_ROWB + DB * 64 + 8 * A_ROWB>(va);
+            VTR(0, 0) VTR(0, 1) VTR(0, 2) VTR(1, 0) VTR(1, 1) VTR(1, 2) VTR(2, 0) VTR(2, 1) VTR(2, 2) VTR(3, 0) VTR(3, 1) VTR(3, 2)
+#undef VTR
         }
         // ---- online softmax: raw-score running max, scale folded into the exp2 argument -----------------
         const int kbase = kt * A_KT;
@@ -149,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
+        STAMP(2)
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new > m_run)) {        // rescale only when some query's running max moved
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
@@ -182,21 +226,34 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
             }
         const float psum = ps2[0] + ps2[1];
         l_run += psum;
+        STAMP(3)
         // ---- O^T += V^T . P^T -------------------------------------------------------------------
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vlo[4]), "+v"(vlo[5]), "+v"(vlo[6]), "+v"(vlo[7]),
+                       "+v"(vlo[8]), "+v"(vlo[9]), "+v"(vlo[10]), "+v"(vlo[11]));
+        asm volatile("" : "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3]), "+v"(vhi[4]), "+v"(vhi[5]), "+v"(vhi[6]), "+v"(vhi[7]),
+                          "+v"(vhi[8]), "+v"(vhi[9]), "+v"(vhi[10]), "+v"(vhi[11]));
 #pragma unroll
         for (int s16 = 0; s16 < 4; ++s16) {
 #pragma unroll
             for (int db = 0; db < 3; ++db) {
-                const char* vp = sV + v_lane_off + s16 * 16 * A_ROWB + db * 64;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(vp));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(vp + 8 * A_ROWB));
+                const bf16x4 lo = vlo[3 * s16 + db], hi = vhi[3 * s16 + db];
                 bf16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
                 o[db] = mfma16(vf, pf[s16], o[db]);
             }
         }
+        STAMP(4)
     }
+#ifdef ATT_STAMP
+    if (LSE && lane == 0) {
+        for (int i = 0; i < 6; ++i) LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + i] = (float)tacc[i] / nkt;
+        LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + 6] = (float)(__builtin_readcyclecounter() - t_begin);
+        LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + 7] = (float)(wall_clock64() - w_begin);
+        return;
+    }
+#endif
     // ---- epilogue: normalise, + q residual, store [b][q][g*96 + d] -------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -315,11 +372,18 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
     if (act_dtype == MVIT_BF16) {
         dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
         const float sl2 = scale * 1.44269504088896340736f;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess)
+                return MVIT_ELAUNCH;
+            attr_done = true;
+        }
         if (add_q)
-            hipLaunchKernelGGL((attn_fwd_bf16_kernel<true>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+            hipLaunchKernelGGL((attn_fwd_bf16_kernel<true>), grid, dim3(256), A_STAGES * A_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
         else
-            hipLaunchKernelGGL((attn_fwd_bf16_kernel<false>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+            hipLaunchKernelGGL((attn_fwd_bf16_kernel<false>), grid, dim3(256), A_STAGES * A_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
     } else if (act_dtype == MVIT_F32) {
         dim3 grid((Lq + 127) / 128, B * heads);

@@ -66,6 +66,12 @@ def main():
                                             _hip.BF16, st))
         ms = timeit(fn, reps)
         print("attn B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s" % (B, h, Lq, Lk, ms * 1e3, 4.0 * B * h * Lq * Lk * 96 / ms / 1e9))
+        if os.environ.get("ATT_STAMP"):      # library built with -DATT_STAMP: per-phase cycle averages land in the LSE buffer
+            lse = torch.zeros(B * h * Lq, device=dev)
+            _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5, 1,
+                                            _hip.BF16, st))
+            t = lse.view(B * h, Lq)[:, :(Lq // 128) * 128].reshape(B * h, Lq // 128, 4, 32)[..., :8].float()
+            print("phase cycles/tile (wait, barrier+dma, S+max, softmax, PV issue, -):", [round(x, 1) for x in t.mean(dim=(0, 1, 2)).tolist()], "sum", round(t.mean(dim=(0, 1, 2)).sum().item(), 1))
     elif op == "pool":
         B, h, T, H, W, s = (int(v) for v in a[:6])
         reps = int(a[6]) if len(a) > 6 else 20
