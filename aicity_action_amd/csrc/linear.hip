@@ -6,6 +6,8 @@
 //   * fp32 path: exact-fp32 LDS-tiled VALU GEMM (parity path, not performance critical).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -422,6 +424,21 @@ static int launch_linear_dma(const void* a, int64_t lda, const void* w, const fl
 #define G_BUF (G_PANEL_A + G_PANEL_B) // 40960
 #define G_SMEM (2 * G_BUF)            // 81920
 
+// LDS fragment reads of the persistent kernel are inline asm: the compiler cannot tell a ds_read from the LDS-DMA
+// writes still in flight for the next slab and (depending on how it peels the loop) puts s_waitcnt vmcnt(0) in front of
+// the first MFMA, which serialises the DMA ring; it also waits lgkmcnt(0) after every other read.  Here all 20 reads
+// of a slab are issued first and each k-step waits only for its own five (LDS returns in order).
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
@@ -479,33 +496,44 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
-    int foff[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t lds_x[4], lds_w[4];       // per-lane LDS byte addresses of the k-step fragments in buffer 0
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
-    const int fx_off = (64 * wm + r) * G_ROWB;                 // token rows  (MFMA B operand)
-    const int fw_off = G_PANEL_A + (96 * wn + r) * G_ROWB;     // weight rows (MFMA A operand)
+    for (int ks = 0; ks < 4; ++ks) {
+        const int fo = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
+        lds_x[ks] = lds0 + (64 * wm + r) * G_ROWB + fo;                 // token rows  (MFMA B operand)
+        lds_w[ks] = lds0 + G_PANEL_A + (96 * wn + r) * G_ROWB + fo;     // weight rows (MFMA A operand)
+    }
 
     const int nk = K / G_BK;
     dma(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
         __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other buffer
-        if (kt + 1 < nk && !(epilogue & 512)) dma((kt + 1) * G_BK, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * G_BUF;
-        if (epilogue & 1024) continue;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 xf[2], wf[3];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(base + fx_off + mb * 32 * G_ROWB + foff[ks]);
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(base + fw_off + nb * 32 * G_ROWB + foff[ks]);
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-                    acc[mb][nb] = mfma16(wf[nb], xf[mb], acc[mb][nb]);
-        }
+        if (kt + 1 < nk) dma((kt + 1) * G_BK, (kt + 1) & 1);
+        const uint32_t bo = (kt & 1) ? G_BUF : 0;
+        bf16x8 xf[4][2], wf[4][3];
+#define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
+                 xf[KS][0] = lds_read128<0>(xa); xf[KS][1] = lds_read128<32 * G_ROWB>(xa); \
+                 wf[KS][0] = lds_read128<0>(wa); wf[KS][1] = lds_read128<32 * G_ROWB>(wa); wf[KS][2] = lds_read128<64 * G_ROWB>(wa); }
+#define MM(KS) _Pragma("unroll") for (int nb = 0; nb < 3; ++nb) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) \
+                 acc[mb][nb] = mfma16(wf[KS][nb], xf[KS][mb], acc[mb][nb]);
+        RD(0) RD(1)
+        lds_wait5<5>(xf[0][0], xf[0][1], wf[0][0], wf[0][1], wf[0][2]);
+        RD(2)
+        MM(0)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait5<5>(xf[1][0], xf[1][1], wf[1][0], wf[1][1], wf[1][2]);
+        RD(3)
+        MM(1)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait5<5>(xf[2][0], xf[2][1], wf[2][0], wf[2][1], wf[2][2]);
+        MM(2)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait5<0>(xf[3][0], xf[3][1], wf[3][0], wf[3][1], wf[3][2]);
+        MM(3)
+#undef RD
+#undef MM
     }
 
     if (epilogue & 256) {   // DIAG build aid: skip the epilogue, keep the accumulators live
@@ -599,7 +627,7 @@ static int launch_linear_big(const void* a, int64_t lda, const void* w, const fl
 // tile start), which leaves the common epilogues (bias, bias+GELU) free of vector loads: the stores trail and the
 // next slab wait uses vmcnt(#stores) instead of vmcnt(0).
 // ------------------------------------------------------------------------------------------------
-template <typename TO>
+template <typename TO, bool GELU>   // bias (optional) [+ GELU]; no residual / row scale (those use linear_big_kernel)
 __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
@@ -633,11 +661,14 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
         const int row = 8 * (6 * wave + i) + (lane >> 3);
         b_off[i] = row * K + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
-    int foff[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t lds_x[4], lds_w[4];       // per-lane LDS byte addresses of the k-step fragments in buffer 0
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
-    const int fx_off = (64 * wm + r) * G_ROWB;                 // token rows  (MFMA B operand)
-    const int fw_off = G_PANEL_A + (96 * wn + r) * G_ROWB;     // weight rows (MFMA A operand)
+    for (int ks = 0; ks < 4; ++ks) {
+        const int fo = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
+        lds_x[ks] = lds0 + (64 * wm + r) * G_ROWB + fo;                 // token rows  (MFMA B operand)
+        lds_w[ks] = lds0 + G_PANEL_A + (96 * wn + r) * G_ROWB + fo;     // weight rows (MFMA A operand)
+    }
     const int nk = K / G_BK;
 
     // per-tile DMA sources
@@ -678,20 +709,25 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
 
         // acc[mb][nb]: rows (registers) = n = 96*wn + 32*nb + (i&3) + 8*(i>>2) + 4*h ; column (lane) = m = 64*wm + 32*mb + r
         f32x16 acc[2][3];
+        if (epilogue & MVIT_EPI_BIAS) {
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
-            const float* bp = bias + n0 + 96 * wn + 32 * nb;      // wave-uniform -> scalar loads
+            for (int nb = 0; nb < 3; ++nb) {
+                const float4* bp = reinterpret_cast<const float4*>(bias + n0 + 96 * wn + 32 * nb);   // wave-uniform -> scalar loads
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float b = 0.f;
-                if (epilogue & MVIT_EPI_BIAS) {
-                    const int c = (i & 3) + 8 * (i >> 2);
-                    const float lo = bp[c], hi = bp[c + 4];
-                    b = h ? hi : lo;
+                for (int g4 = 0; g4 < 4; ++g4) {      // registers 4g..4g+3 = columns 8g + 4h + (0..3)
+                    const float4 lo = bp[2 * g4], hi = bp[2 * g4 + 1];
+                    const float b0 = h ? hi.x : lo.x, b1 = h ? hi.y : lo.y, b2 = h ? hi.z : lo.z, b3 = h ? hi.w : lo.w;
+                    acc[0][nb][4 * g4 + 0] = b0; acc[1][nb][4 * g4 + 0] = b0;
+                    acc[0][nb][4 * g4 + 1] = b1; acc[1][nb][4 * g4 + 1] = b1;
+                    acc[0][nb][4 * g4 + 2] = b2; acc[1][nb][4 * g4 + 2] = b2;
+                    acc[0][nb][4 * g4 + 3] = b3; acc[1][nb][4 * g4 + 3] = b3;
                 }
-                acc[0][nb][i] = b;
-                acc[1][nb][i] = b;
             }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc[0][nb][i] = 0.f; acc[1][nb][i] = 0.f; }
         }
 
         for (int kt = 0; kt < nk; ++kt, ++s) {
@@ -700,29 +736,38 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
             __builtin_amdgcn_s_barrier();                          // everyone's have; the other buffer is free
             if (kt + 1 < nk) dma((kt + 1) * G_BK, (s + 1) & 1);
             else if (has_next) { setup(t_next); dma(0, (s + 1) & 1); }
-            const char* base = smem + (s & 1) * G_BUF;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 xf[2], wf[3];
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) xf[mb] = *reinterpret_cast<const bf16x8*>(base + fx_off + mb * 32 * G_ROWB + foff[ks]);
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(base + fw_off + nb * 32 * G_ROWB + foff[ks]);
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-                        acc[mb][nb] = mfma16(wf[nb], xf[mb], acc[mb][nb]);
-            }
+            const uint32_t bo = (s & 1) ? G_BUF : 0;
+            bf16x8 xf[4][2], wf[4][3];
+#define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
+                 xf[KS][0] = lds_read128<0>(xa); xf[KS][1] = lds_read128<32 * G_ROWB>(xa); \
+                 wf[KS][0] = lds_read128<0>(wa); wf[KS][1] = lds_read128<32 * G_ROWB>(wa); wf[KS][2] = lds_read128<64 * G_ROWB>(wa); }
+#define MM(KS) _Pragma("unroll") for (int nb = 0; nb < 3; ++nb) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) \
+                 acc[mb][nb] = mfma16(wf[KS][nb], xf[KS][mb], acc[mb][nb]);
+            // fragment pipeline: two k-steps of reads in flight ahead of the MFMAs (LDS returns in order)
+            RD(0) RD(1)
+            lds_wait5<5>(xf[0][0], xf[0][1], wf[0][0], wf[0][1], wf[0][2]);
+            RD(2)
+            MM(0)
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait5<5>(xf[1][0], xf[1][1], wf[1][0], wf[1][1], wf[1][2]);
+            RD(3)
+            MM(1)
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait5<5>(xf[2][0], xf[2][1], wf[2][0], wf[2][1], wf[2][2]);
+            MM(2)
+            __builtin_amdgcn_sched_barrier(0);
+            lds_wait5<0>(xf[3][0], xf[3][1], wf[3][0], wf[3][1], wf[3][2]);
+            MM(3)
+#undef RD
+#undef MM
         }
 
         // ---- epilogue from registers: lane = output row, quads of 4 consecutive columns ------------------
-        const bool loads_in_epilogue = row_scale || (epilogue & MVIT_EPI_RESIDUAL);
+        auto emit = [&](auto full_tag) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int64_t m = m0 + 64 * wm + 32 * mb + r;
-            const bool ok = full_m || m < M;
-            const float sc = (row_scale && ok) ? row_scale[m / rows_per_scale] : 1.f;
+            const bool ok = decltype(full_tag)::value || m < M;
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) {
                 const int nbase = n0 + 96 * wn + 32 * nb + 4 * h;    // + 8*q
@@ -730,25 +775,17 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     v[qd] = make_float4(acc[mb][nb][4 * qd], acc[mb][nb][4 * qd + 1], acc[mb][nb][4 * qd + 2], acc[mb][nb][4 * qd + 3]);
-                    if (epilogue & MVIT_EPI_GELU) {
+                    if (GELU) {
                         v[qd].x = gelu_fast(v[qd].x); v[qd].y = gelu_fast(v[qd].y);
                         v[qd].z = gelu_fast(v[qd].z); v[qd].w = gelu_fast(v[qd].w);
                     }
-                    if (row_scale) { v[qd].x *= sc; v[qd].y *= sc; v[qd].z *= sc; v[qd].w *= sc; }
                 }
                 if constexpr (sizeof(TO) == 4) {
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        if (ok) {
-                            if (epilogue & MVIT_EPI_RESIDUAL) {
-                                const float4 rr = load4(residual + m * ldr + nbase + 8 * qd);
-                                v[qd].x += rr.x; v[qd].y += rr.y; v[qd].z += rr.z; v[qd].w += rr.w;
-                            }
-                            *reinterpret_cast<float4*>(y + m * ldy + nbase + 8 * qd) = v[qd];
-                        }
-                    }
+                    for (int qd = 0; qd < 4; ++qd)
+                        if (ok) *reinterpret_cast<float4*>(y + m * ldy + nbase + 8 * qd) = v[qd];
                 } else {
-                    // 16-bit out (no residual): pair the quads of the two half-waves with permlane32_swap -> 16-B pieces
+                    // 16-bit out: pair the quads of the two half-waves with permlane32_swap -> 16-B pieces
 #pragma unroll
                     for (int qd = 0; qd < 4; qd += 2) {
                         uint32_t a0 = pack_bf16x2(v[qd].x, v[qd].y), a1 = pack_bf16x2(v[qd].z, v[qd].w);
@@ -761,15 +798,15 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
                 }
             }
         }
+        };
+        if (full_m) emit(std::true_type{}); else emit(std::false_type{});
         if (!has_next) break;
-        // stores trail behind the already-issued slab-0 DMA only when nothing in the epilogue had to wait on a load
-        trail = full_m && !loads_in_epilogue;
-        if (!trail) { /* epilogue loads already forced the DMA to land; stores may still be in flight */ }
+        trail = full_m;     // exactly NST stores were issued behind the slab-0 DMA of the next tile
         t = t_next;
     }
 }
 
-template <typename TO>
+template <typename TO, bool GELU>
 static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
                               int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
                               int K, int epi, hipStream_t st) {
@@ -777,14 +814,14 @@ static int launch_linear_pers(const void* a, int64_t lda, const void* w, const f
     if (nt > 0x7fffffff) return MVIT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO, GELU>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
     const int64_t q = (nt + 7) / 8;
     const int per = (int)(q < 64 ? q : 64);             // 2 workgroups per CU x 32 CUs per XCD
-    hipLaunchKernelGGL((linear_pers_kernel<TO>), dim3((unsigned)(8 * per)), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+    hipLaunchKernelGGL((linear_pers_kernel<TO, GELU>), dim3((unsigned)(8 * per)), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
                        (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
@@ -914,10 +951,10 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         // one-tile-per-workgroup form overlaps them better)
         static const bool pers_env = getenv("MVIT_GEMM_NO_PERS") == nullptr;
         const bool use_pers = pers_env && !row_scale && !(epilogue & MVIT_EPI_RESIDUAL);
-        if (use_pers && out_dtype == MVIT_BF16)
-            return launch_linear_pers<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
-        if (use_pers && out_dtype == MVIT_F32)
-            return launch_linear_pers<float>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
+#define PERS(TO, G) return launch_linear_pers<TO, G>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
+        if (use_pers && out_dtype == MVIT_BF16) { if (epilogue & MVIT_EPI_GELU) PERS(bf16_t, true); else PERS(bf16_t, false); }
+        if (use_pers && out_dtype == MVIT_F32) { if (epilogue & MVIT_EPI_GELU) PERS(float, true); else PERS(float, false); }
+#undef PERS
         if (out_dtype == MVIT_BF16)
             return launch_linear_big<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
         if (out_dtype == MVIT_F32)
