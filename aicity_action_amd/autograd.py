@@ -73,6 +73,15 @@ class _Ctx(object):
                                             _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
         return dW, db
 
+    def scaled16(self, dy, row_scale=None, rps=0):
+        """fp32 gradient (times its drop-path factor) as the 16-bit GEMM operand; (tensor, row_scale, rps) to pass on."""
+        if self.act == _hip.F32:
+            return dy, row_scale, rps
+        out = torch.empty(dy.shape, dtype=self.adt, device=dy.device)
+        _hip.check(self.L.mvit_cast_rows_f32_to_bf16(_hip.ptr(dy), _hip.ptr(out), dy.shape[0], dy.shape[1], _hip.ptr(row_scale), rps,
+                                                     _st()), "cast_rows")
+        return out, None, 0
+
     def colsum(self, dy, row_scale=None, rps=0):
         M, N = dy.shape
         out = torch.empty(N, dtype=torch.float32, device=dy.device)
@@ -201,8 +210,10 @@ class _BlockFn(torch.autograd.Function):
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         d_out = d_out.contiguous().view(Mq, Cout)
         # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
-        dW2, db2 = hx.wgrad(hid, d_out, Cout, 4 * Cout, dp2, Lq)
-        d_hid = hx.linear(d_out, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=dp2, rps=Lq)
+        g16, gs, grps = hx.scaled16(d_out, dp2, Lq)
+        dW2, db2 = hx.wgrad(hid, g16, Cout, 4 * Cout, gs, grps)
+        d_hid = hx.linear(g16, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=gs, rps=grps)
+        del g16
         d_pre = torch.empty_like(d_hid)
         _hip.check(L.mvit_gelu_bwd(_hip.ptr(pre), _hip.ptr(d_hid), _hip.ptr(d_pre), pre.numel(), act, _st()), "gelu_bwd")
         del d_hid
@@ -213,8 +224,10 @@ class _BlockFn(torch.autograd.Function):
         dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, True)
         del d_vn
         # ---- attention branch: y = r + dp1 * proj(o) ------------------------------------------------------
-        dWp, dbp = hx.wgrad(o, d_y, Cout, Cout, dp1, Lq)
-        d_o = hx.linear(d_y, hx.wt(at.proj.weight), None, adt, row_scale=dp1, rps=Lq)
+        g16, gs, grps = hx.scaled16(d_y, dp1, Lq)
+        dWp, dbp = hx.wgrad(o, g16, Cout, Cout, gs, grps)
+        d_o = hx.linear(g16, hx.wt(at.proj.weight), None, adt, row_scale=gs, rps=grps)
+        del g16
         dq = torch.empty_like(q)
         dk = torch.empty_like(k)
         dv = torch.empty_like(v)

@@ -6,6 +6,8 @@
 //     add their partial tiles to dW with fp32 atomics (128 B contiguous per half-wave; dW is tiny next to M).
 //   * fp32 path: exact VALU kernel (parity path).
 // dy may carry a per-sample drop-path factor (row_scale), applied while staging.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((address_space(3))) bf16x4 lds_b4;
@@ -137,6 +139,170 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-tile weight gradient: dW[n0:+128][k0:+192] += sum over an M chunk of dy[m][n]^T a[m][k] (both operands bf16,
+// row-major over m, so the contraction index is the ROW index of both).  Same skeleton as linear_big_kernel:
+// 4 waves (2 x 2, 64n x 96k each), 64-row slabs (dy: 256-B row pieces, a: 384-B) double-buffered in LDS by
+// global_load_lds_dwordx4, fragments by ds_read_b64_tr_b16 (transposing read: 8 consecutive m of one column), issued as
+// inline asm two k-steps ahead of the MFMAs with counted lgkmcnt waits.
+// LDS images: 64-byte segments of a row are XOR-permuted so that the four rows a transposing read touches fall in
+// different bank ranges: dy image (256-B rows) seg ^= row&3, a image (384-B rows) seg ^= (row>>1)&1; the DMA applies
+// the permutation to the SOURCE address, the reads to the LDS address.
+// Partial tiles of the M chunks are summed with fp32 atomics (dW zeroed by the caller), db through a ones-MFMA.
+// ------------------------------------------------------------------------------------------------
+#define WB_BP 128
+#define WB_BQ 192
+#define WB_PROWB 256
+#define WB_QROWB 384
+#define WB_PANEL_P (64 * WB_PROWB)    // 16384
+#define WB_PANEL_Q (64 * WB_QROWB)    // 24576
+#define WB_BUF (WB_PANEL_P + WB_PANEL_Q)
+#define WB_SMEM (2 * WB_BUF)
+
+typedef __attribute__((address_space(1))) const void wb_gptr_t;
+typedef __attribute__((address_space(3))) void wb_lptr_t;
+
+template <int OFF>
+__device__ __forceinline__ bf16x4 wb_tr(uint32_t addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+#define wb_wait5(F, N) \
+    asm volatile("s_waitcnt lgkmcnt(%10)" \
+                 : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1]), \
+                   "+v"(F[4][0]), "+v"(F[4][1]) \
+                 : "n"(N))
+__device__ __forceinline__ bf16x8 wb_join(const bf16x4 (&f)[2]) {
+    bf16x8 v;
+    v[0] = f[0][0]; v[1] = f[0][1]; v[2] = f[0][2]; v[3] = f[0][3];
+    v[4] = f[1][0]; v[5] = f[1][1]; v[6] = f[1][2]; v[7] = f[1][3];
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restrict__ a, int64_t lda,
+                                                           const bf16_t* __restrict__ dy, int64_t ldd,
+                                                           float* __restrict__ dW, float* __restrict__ db, int64_t M, int N,
+                                                           int K, int mchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntq = K / WB_BQ;
+    const int n0 = (blockIdx.x / ntq) * WB_BP, k0 = (blockIdx.x % ntq) * WB_BQ;
+    const int64_t mbeg = (int64_t)blockIdx.y * mchunk;
+    const int64_t mend = mbeg + mchunk < M ? mbeg + mchunk : M;     // multiple of 64 (checked by the launcher)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const bool do_bias = db != nullptr && k0 == 0 && wq == 0;       // wave-uniform
+
+    // DMA sources (per lane, relative to the slab's first row)
+    int64_t p_src[4], q_src[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // dy image: piece = 4 rows x 256 B
+        const int row = 4 * (4 * wave + i) + (lane >> 4), c = lane & 15;
+        const int seg = (c >> 2) ^ (row & 3);
+        p_src[i] = (int64_t)row * ldd + n0 + 8 * (4 * seg + (c & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {       // a image: 24 chunks per row, pieces run across rows
+        const int x = 64 * (6 * wave + i) + lane;
+        const int row = x / 24, c = x - row * 24;
+        const int seg = (c >> 2) ^ ((row >> 1) & 1);
+        q_src[i] = (int64_t)row * lda + k0 + 8 * (4 * seg + (c & 3));
+    }
+    auto dma = [&](int64_t m0, int buf) {
+        char* base = smem + buf * WB_BUF;
+        const bf16_t* ps = dy + m0 * ldd;
+        const bf16_t* qs = a + m0 * lda;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((wb_gptr_t*)(ps + p_src[i]), (wb_lptr_t*)(base + 1024 * (4 * wave + i)), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((wb_gptr_t*)(qs + q_src[i]), (wb_lptr_t*)(base + WB_PANEL_P + 1024 * (6 * wave + i)), 16, 0, 0);
+    };
+
+    // transposing fragment reads: lane supplies row 8h + (i16>>2) (+4 for the second half) and 8 bytes at
+    // 32*(gi&1) + 8*(i16&3) inside the 64-byte segment of its 32-column block
+    const int i16 = lane & 15, gi = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int rr = 8 * h + (i16 >> 2), inseg = 32 * (gi & 1) + 8 * (i16 & 3);
+    uint32_t pa[2], qa[3];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) pa[pb] = lds0 + rr * WB_PROWB + 64 * ((2 * wp + pb) ^ (i16 >> 2)) + inseg;
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) qa[qb] = lds0 + WB_PANEL_P + rr * WB_QROWB + 64 * ((3 * wq + qb) ^ ((i16 >> 3) & 1)) + inseg;
+
+    f32x16 acc[2][3], bacc[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[pb][i] = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pb][qb][i] = 0.f;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = MVIT_ONE16;
+
+    const int nslab = (int)((mend - mbeg) / 64);
+    dma(mbeg, 0);
+    for (int sl = 0; sl < nslab; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (sl + 1 < nslab) dma(mbeg + 64 * (int64_t)(sl + 1), (sl + 1) & 1);
+        const uint32_t bo = (sl & 1) ? WB_BUF : 0;
+        bf16x4 f[4][5][2];      // [k-step][P0 P1 Q0 Q1 Q2][lo hi]
+#define RD(KS) { \
+            f[KS][0][0] = wb_tr<KS * 16 * WB_PROWB>(pa[0] + bo); f[KS][0][1] = wb_tr<KS * 16 * WB_PROWB + 4 * WB_PROWB>(pa[0] + bo); \
+            f[KS][1][0] = wb_tr<KS * 16 * WB_PROWB>(pa[1] + bo); f[KS][1][1] = wb_tr<KS * 16 * WB_PROWB + 4 * WB_PROWB>(pa[1] + bo); \
+            f[KS][2][0] = wb_tr<KS * 16 * WB_QROWB>(qa[0] + bo); f[KS][2][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[0] + bo); \
+            f[KS][3][0] = wb_tr<KS * 16 * WB_QROWB>(qa[1] + bo); f[KS][3][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[1] + bo); \
+            f[KS][4][0] = wb_tr<KS * 16 * WB_QROWB>(qa[2] + bo); f[KS][4][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[2] + bo); }
+#define MM(KS) { \
+            const bf16x8 p0 = wb_join(f[KS][0]), p1 = wb_join(f[KS][1]); \
+            const bf16x8 q0 = wb_join(f[KS][2]), q1 = wb_join(f[KS][3]), q2 = wb_join(f[KS][4]); \
+            acc[0][0] = mfma16(p0, q0, acc[0][0]); acc[1][0] = mfma16(p1, q0, acc[1][0]); \
+            acc[0][1] = mfma16(p0, q1, acc[0][1]); acc[1][1] = mfma16(p1, q1, acc[1][1]); \
+            acc[0][2] = mfma16(p0, q2, acc[0][2]); acc[1][2] = mfma16(p1, q2, acc[1][2]); \
+            if (do_bias) { bacc[0] = mfma16(p0, ones, bacc[0]); bacc[1] = mfma16(p1, ones, bacc[1]); } }
+        RD(0) RD(1)
+        wb_wait5(f[0], 10);
+        RD(2)
+        MM(0)
+        __builtin_amdgcn_sched_barrier(0);
+        wb_wait5(f[1], 10);
+        RD(3)
+        MM(1)
+        __builtin_amdgcn_sched_barrier(0);
+        wb_wait5(f[2], 10);
+        MM(2)
+        __builtin_amdgcn_sched_barrier(0);
+        wb_wait5(f[3], 0);
+        MM(3)
+#undef RD
+#undef MM
+    }
+    // acc[pb][qb][i]: row n = n0 + 64wp + 32pb + (i&3) + 8(i>>2) + 4h, col k = k0 + 96wq + 32qb + r -> 128 contiguous bytes
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                atomicAdd(dW + (int64_t)n * K + k0 + 96 * wq + 32 * qb + r, acc[pb][qb][i]);
+            }
+    if (do_bias && r == 0) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(db + n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h, bacc[pb][i]);
+    }
+}
+
 // exact fp32: 64(n) x 64(k) tile per block over an M chunk, 4x4 per thread
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy,
                                                         int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
@@ -221,6 +387,25 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
     }
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return MVIT_EUNSUPPORTED;
+    static const bool use_big = getenv("MVIT_WGRAD_NO_BIG") == nullptr;
+    if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !row_scale && N % WB_BP == 0 && K % WB_BQ == 0 && M % 64 == 0 &&
+        64 * lda < (1ll << 31) && 64 * ldd < (1ll << 31)) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess)
+                return MVIT_ELAUNCH;
+            attr_done = true;
+        }
+        const int64_t bt = (int64_t)(N / WB_BP) * (K / WB_BQ);
+        int64_t nch = (512 + bt - 1) / bt;                      // ~2 workgroups per CU in total
+        int64_t bmc = ((M / 64 + nch - 1) / nch) * 64;          // rows per chunk, multiple of 64
+        if (bmc < 512) bmc = 512;
+        nch = (M + bmc - 1) / bmc;
+        dim3 bgrid((unsigned)bt, (unsigned)nch);
+        hipLaunchKernelGGL(wgrad_big_kernel, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K, (int)bmc);
+        MVIT_LAUNCH_CHECK();
+        return MVIT_OK;
+    }
     dim3 grid((N / 96) * (K / 96), (unsigned)mchunks);
 #define WG(TA, TD) \
     hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(192), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, db, M, N, K, mchunk)

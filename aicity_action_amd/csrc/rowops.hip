@@ -285,6 +285,35 @@ extern "C" int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, voi
     return MVIT_OK;
 }
 
+// rows x cols fp32 -> 16-bit with an optional per-row-group factor (drop-path scale of the gradient that feeds the
+// weight- and data-gradient GEMMs); cols % 8 == 0, 32 B in / 16 B out per thread.
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t rows, int cols8,
+                                                        const float* __restrict__ row_scale, int64_t rps) {
+    const int64_t n8 = rows * cols8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float sc = row_scale ? row_scale[(i / cols8) / rps] : 1.0f;
+        float4 lo, hi;
+        load8(s + 8 * i, lo, hi);
+        uint4 o;
+        o.x = pack_bf16x2(lo.x * sc, lo.y * sc); o.y = pack_bf16x2(lo.z * sc, lo.w * sc);
+        o.z = pack_bf16x2(hi.x * sc, hi.y * sc); o.w = pack_bf16x2(hi.z * sc, hi.w * sc);
+        *reinterpret_cast<uint4*>(d + 8 * i) = o;
+    }
+}
+
+extern "C" int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols, const float* row_scale,
+                                          int64_t rows_per_scale, void* stream) {
+    if (!src || !dst || rows < 0 || cols <= 0 || (row_scale && rows_per_scale <= 0)) return MVIT_EINVAL;
+    if (cols % 8) return MVIT_EUNSUPPORTED;
+    if (rows == 0) return MVIT_OK;
+    int64_t blocks = (rows * (cols / 8) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, (bf16_t*)dst, rows, cols / 8,
+                       row_scale, rows_per_scale);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 #ifdef MVIT_HALF_IS_FP16
 extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: fp16)"; }
 #else

@@ -197,6 +197,12 @@ int mvit_window_preprocess(const void* frames, const int* frame_idx, float* out,
 /* fp32 -> bf16 (round to nearest even) conversion of parameters, n elements. */
 int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* dst[r][c] = (16-bit) (row_scale ? row_scale[r / rows_per_scale] : 1) * src[r][c]; cols % 8 == 0.  Training only: the fp32
+ * residual-stream gradient times its drop-path factor (reference: slowfast/models/common.py:46-59 backward) as the
+ * 16-bit operand of the weight- and data-gradient GEMMs of proj / fc2 (attention.py:281,445 backward). */
+int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols, const float* row_scale,
+                               int64_t rows_per_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,10 +89,24 @@ def test_gelu_fwd_bwd(hip_lib, act):
     _close(dx, xr.grad, tol)
 
 
+@pytest.mark.parametrize("rows,cols,rps", [(1000, 96, 0), (777, 384, 100), (64, 768, 64)])
+def test_cast_rows_with_drop_path_scale(hip_lib, rows, cols, rps):
+    x = _rnd(rows, cols, seed=31)
+    sc = torch.rand((rows + rps - 1) // rps, generator=torch.Generator().manual_seed(5)) * 2 if rps else None
+    ref = (x * (sc.repeat_interleave(rps)[:rows, None] if rps else 1.0)).to(torch.bfloat16)
+    xd = x.to(DEV)
+    scd = sc.to(DEV) if rps else None
+    out = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_cast_rows_f32_to_bf16(_hip.ptr(xd), _hip.ptr(out), rows, cols, _hip.ptr(scd), rps, _st()))
+    assert torch.equal(out.cpu(), ref)       # same fp32 product, same round-to-nearest-even
+    assert hip_lib.mvit_cast_rows_f32_to_bf16(_hip.ptr(xd), _hip.ptr(out), rows, 100, None, 0, _st()) == -4
+
+
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("M,N,K,scaled", [(1000, 288, 96, False), (2500, 96, 384, True), (129, 384, 192, False),
                                            (3000, 192, 768, True), (700, 576, 192, False), (300, 768, 96, False),
-                                           (300, 1152, 96, False)])
+                                           (300, 1152, 96, False), (4096, 384, 384, False), (6336, 384, 192, False),
+                                           (64, 384, 192, False)])
 def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
     a = _act(_rnd(M, K, seed=11), act)
     for dy_f32 in ([True] if act == _hip.F32 else [True, False]):

@@ -72,6 +72,19 @@ def main():
                                             _hip.BF16, st))
             t = lse.view(B * h, Lq)[:, :(Lq // 128) * 128].reshape(B * h, Lq // 128, 4, 32)[..., :8].float()
             print("phase cycles/tile (wait, barrier+dma, S+max, softmax, PV issue, -):", [round(x, 1) for x in t.mean(dim=(0, 1, 2)).tolist()], "sum", round(t.mean(dim=(0, 1, 2)).sum().item(), 1))
+    elif op == "wgrad":
+        M, N, K = int(a[0]), int(a[1]), int(a[2])
+        reps = int(a[3]) if len(a) > 3 else 20
+        x = torch.randn(M, K, device=dev).bfloat16()
+        dy = torch.randn(M, N, device=dev).bfloat16()
+        dW = torch.zeros(N, K, device=dev)
+        db = torch.zeros(N, device=dev)
+
+        def fn():
+            _hip.check(L.mvit_linear_wgrad(_hip.ptr(x), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
+                                           _hip.BF16, st))
+        ms = timeit(fn, reps)
+        print("wgrad M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s" % (M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
     elif op == "pool":
         B, h, T, H, W, s = (int(v) for v in a[:6])
         reps = int(a[6]) if len(a) > 6 else 20
