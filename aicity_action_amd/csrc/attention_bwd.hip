@@ -307,25 +307,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         if (tid < 128) sL[tid] = rl;
         __syncthreads();
         if (qt + 1 < nqt) gload((qt + 1) * B_T);
-        // S = Q . K^T  and dP = dO . V^T   (rows = queries in registers, column = this lane's key)
-        f32x16 s[2], dp[2];
+        // per 32-query block (keeps one S / dP accumulator pair live: the kernel fits 2 waves per SIMD):
+        //   S = Q . K^T and dP = dO . V^T (rows = queries in registers, column = this lane's key), P / dS in registers,
+        //   then dV^T += dO^T . P and dK^T += Q^T . dS for the block's two 16-query k-steps
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
             const char* qr = sQ + (32 * qb + r) * B_ROWB;
             const char* dr = sD + (32 * qb + r) * B_ROWB;
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qr + roff[ks]);
                 const bf16x8 df = *reinterpret_cast<const bf16x8*>(dr + roff[ks]);
-                s[qb] = mfma16(qf, kf[ks], s[qb]);
-                dp[qb] = mfma16(df, vf[ks], dp[qb]);
+                s = mfma16(qf, kf[ks], s);
+                dp = mfma16(df, vf[ks], dp);
             }
-        }
-        bf16x8 pf[4], dsf[4];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float pv[8], dsv[8];
@@ -340,24 +339,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 8 * sh + 4 * g4 + e;
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][i], scale_log2e, -ls[e]));
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], scale_log2e, -ls[e]));
                         pv[4 * g4 + e] = p;
-                        dsv[4 * g4 + e] = p * (dp[qb][i] - ds4[e]);
+                        dsv[4 * g4 + e] = p * (dp[i] - ds4[e]);
                     }
                 }
-                pf[2 * qb + sh] = pack8(pv);
-                dsf[2 * qb + sh] = pack8(dsv);
+                pf[sh] = pack8(pv);
+                dsf[sh] = pack8(dsv);
             }
-        // dV^T += dO^T . P ;  dK^T += Q^T . dS
 #pragma unroll
-        for (int s16 = 0; s16 < 4; ++s16)
+            for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
-            for (int db = 0; db < 3; ++db) {
-                const bf16x8 dof = tr_frag(sDp + t_lane + s16 * 16 * B_ROWB + db * 64);
-                const bf16x8 qtf = tr_frag(sQp + t_lane + s16 * 16 * B_ROWB + db * 64);
-                dv[db] = mfma16(dof, pf[s16], dv[db]);
-                dk[db] = mfma16(qtf, dsf[s16], dk[db]);
-            }
+                for (int db = 0; db < 3; ++db) {
+                    const bf16x8 dof = tr_frag(sDp + t_lane + (2 * qb + sh) * 16 * B_ROWB + db * 64);
+                    const bf16x8 qtf = tr_frag(sQp + t_lane + (2 * qb + sh) * 16 * B_ROWB + db * 64);
+                    dv[db] = mfma16(dof, pf[sh], dv[db]);
+                    dk[db] = mfma16(qtf, dsf[sh], dk[db]);
+                }
+        }
     }
     if (SPLIT) {
         if (k_ok) {
