@@ -184,7 +184,9 @@ class _BlockFn(torch.autograd.Function):
         if not g.skip_is_identity:
             r_full = r
             r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
-            _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r_full), _hip.ptr(r), B, T, H, W, Cout, _st()), "maxpool")
+            pool_idx = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
+            _hip.check(L.mvit_maxpool_skip_fwd_idx(_hip.ptr(r_full), _hip.ptr(r), _hip.ptr(pool_idx), B, T, H, W, Cout, _st()), "maxpool")
+            r_full = pool_idx        # the backward only needs the argmax positions
         y = hx.linear(o, hx.w(at.proj.weight), at.proj.bias, torch.float32, residual=r, row_scale=dp1, rps=Lq)
         vn = hx.ln_fwd(y, blk.norm2)
         pre = hx.linear(vn, hx.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, adt)
@@ -259,7 +261,7 @@ class _BlockFn(torch.autograd.Function):
         d_r = d_y
         if r_full is not None:
             d_rf = torch.empty(M, Cout, dtype=torch.float32, device=dev)
-            _hip.check(L.mvit_maxpool_skip_bwd(_hip.ptr(r_full), _hip.ptr(d_r), _hip.ptr(d_rf), B, T, H, W, Cout, _st()), "maxpool_bwd")
+            _hip.check(L.mvit_maxpool_skip_bwd_idx(_hip.ptr(r_full), _hip.ptr(d_r), _hip.ptr(d_rf), B, T, H, W, Cout, _st()), "maxpool_bwd")
             d_r = d_rf
         extra = []
         if g.expand:

@@ -283,6 +283,91 @@ extern "C" int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx,
 }
 
 // ----------------------------------------------------------------------------------------------
+// Training form of the skip max-pool: the forward also records, per output element, which of the 9 window positions
+// held the FIRST maximum (ATen scan order ky,kx); the backward then reads one index byte + one gradient per window an
+// input belongs to (1, 2 or 4 windows) instead of re-scanning the windows.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_skip_idx_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               uint32_t* __restrict__ idx, int BT, int H, int W, int Ho, int Wo, int C4) {
+    const int64_t total = (int64_t)BT * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t tok = i / C4;
+        const int xo = (int)(tok % Wo); tok /= Wo;
+        const int yo = (int)(tok % Ho);
+        const int64_t bt = tok / Ho;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uint32_t bx = 0, by = 0, bz = 0, bw = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yi = 2 * yo + ky - 1;
+            if (yi < 0 || yi >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xi = 2 * xo + kx - 1;
+                if (xi < 0 || xi >= W) continue;
+                const uint32_t w = ky * 3 + kx;
+                const float4 v = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
+                if (v.x > m.x) { m.x = v.x; bx = w; }
+                if (v.y > m.y) { m.y = v.y; by = w; }
+                if (v.z > m.z) { m.z = v.z; bz = w; }
+                if (v.w > m.w) { m.w = v.w; bw = w; }
+            }
+        }
+        store4(y + i * 4, m);
+        idx[i] = bx | (by << 8) | (bz << 16) | (bw << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_skip_bwd_idx_kernel(const uint32_t* __restrict__ idx, const float* __restrict__ dy,
+                                                                   float* __restrict__ dx, int BT, int H, int W, int Ho, int Wo, int C4) {
+    const int64_t total = (int64_t)BT * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t tok = i / C4;
+        const int xi = (int)(tok % W); tok /= W;
+        const int yi = (int)(tok % H);
+        const int64_t bt = tok / H;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int yo = yi / 2; yo <= (yi + 1) / 2; ++yo) {
+            if (yo >= Ho) continue;
+            for (int xo = xi / 2; xo <= (xi + 1) / 2; ++xo) {
+                if (xo >= Wo) continue;
+                const uint32_t me = (uint32_t)((yi - 2 * yo + 1) * 3 + (xi - 2 * xo + 1));
+                const int64_t o = ((bt * Ho + yo) * Wo + xo) * C4 + c4;
+                const uint32_t w = idx[o];
+                const float4 g = load4(dy + o * 4);
+                if ((w & 255u) == me) acc.x += g.x;
+                if (((w >> 8) & 255u) == me) acc.y += g.y;
+                if (((w >> 16) & 255u) == me) acc.z += g.z;
+                if ((w >> 24) == me) acc.w += g.w;
+            }
+        }
+        store4(dx + i * 4, acc);
+    }
+}
+
+extern "C" int mvit_maxpool_skip_fwd_idx(const float* x, float* y, void* idx, int B, int T, int H, int W, int C, void* stream) {
+    if (!x || !y || !idx || B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MVIT_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)B * T * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_skip_idx_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), x, y, (uint32_t*)idx, B * T, H, W,
+                       Ho, Wo, C / 4);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream) {
+    if (!idx || !dy || !dx || B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MVIT_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)B * T * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_skip_bwd_idx_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), (const uint32_t*)idx, dy, dx,
+                       B * T, H, W, Ho, Wo, C / 4);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Column sums: out[n] (+)= scale-weighted sum over rows of a[M][N]  (bias gradients; two-stage).
 // ----------------------------------------------------------------------------------------------
 #define CS_MAXBLK 256

@@ -158,22 +158,41 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__
     block_reduce(ab, 1);
 }
 
-// out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b
+// out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b.  blockIdx.y slices the partial
+// rows (a few thousand rows of 96..2592 floats: one column block per workgroup cannot pull the bandwidth); with more than one
+// slice the slices meet in fp32 atomics on the (pre-zeroed or accumulated-into) output.
 __global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nparts, int width, float* __restrict__ out_a,
                                                           float* __restrict__ out_b, int split, int accumulate) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + col;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
     float s = 0.f;
     if (j < width)
-        for (int b = sl; b < nparts; b += 4) s += part[(int64_t)b * width + j];
+        for (int b = b0 + sl; b < b1; b += 4) s += part[(int64_t)b * width + j];
     red[sl][col] = s;
     __syncthreads();
     if (sl == 0 && j < width) {
         s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         float* o = (j < split) ? out_a + j : out_b + (j - split);
-        *o = accumulate ? *o + s : s;
+        if (gridDim.y > 1) atomicAdd(o, s);
+        else *o = accumulate ? *o + s : s;
     }
+}
+
+static int launch_pool_reduce(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
+                              hipStream_t st) {
+    int slices = nparts / 64;
+    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+    if (slices > 1 && !accumulate) {
+        if (hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)(split < width ? split : width), st) != hipSuccess) return MVIT_ELAUNCH;
+        if (width > split && hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)(width - split), st) != hipSuccess) return MVIT_ELAUNCH;
+    }
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
+                       accumulate);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
 }
 
 template <typename TA>
@@ -352,8 +371,7 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
         const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
                                                           H, W, stride_hw, eps, act_dtype, st);                            \
         if (nrows < 0) return nrows;                                                                                       \
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3(2), dim3(256), 0, st, workspace, nrows, 96, dgamma, dgamma, 96, accumulate_param); \
-        MVIT_LAUNCH_CHECK();                                                                                               \
+        { const int rr_ = launch_pool_reduce(workspace, nrows, 96, dgamma, dgamma, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
         /* d_beta = column sums of dout (workspace rows are free again after the reduce above, same stream) */             \
         const int rcb = mvit_colsum(dout, act_dtype, tot_out, 96, nullptr, 0, dbeta, accumulate_param, workspace, stream);  \
         if (rcb != MVIT_OK) return rcb;                                                                                    \
@@ -361,8 +379,7 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
         hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w, \
                            gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);      \
         MVIT_LAUNCH_CHECK();                                                                                               \
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3(3), dim3(256), 0, st, workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param); \
-        MVIT_LAUNCH_CHECK();                                                                                               \
+        { const int rr_ = launch_pool_reduce(workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
     }                                                                                                                      \
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
@@ -371,14 +388,12 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
         const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
                                                       act_dtype, st);                                                      \
         if (wr < 0) return wr;                                                                                             \
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, wr, 2592, dw, dw, 2592, 1);               \
-        MVIT_LAUNCH_CHECK();                                                                                               \
+        { const int rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, st); if (rr_ != MVIT_OK) return rr_; }       \
     } else {                                                                                                               \
         hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, st, (const TA*)qkv, ld, chan_off,     \
                            (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                 \
         MVIT_LAUNCH_CHECK();                                                                                               \
-        hipLaunchKernelGGL(pool_reduce_kernel, dim3(41), dim3(256), 0, st, wpart, (int)b3, 2592, dw, dw, 2592, 1);          \
-        MVIT_LAUNCH_CHECK();                                                                                               \
+        { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, st); if (rr_ != MVIT_OK) return rr_; }  \
     }
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN

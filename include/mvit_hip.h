@@ -159,6 +159,11 @@ int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float
 /* Backward of mvit_maxpool_skip_fwd: gradient goes to the first maximum of each window (ATen semantics). */
 int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
 
+/* Training pair of the skip max-pool (attention.py:316-318,427-432): the forward also writes idx [B][T][Ho][Wo][C] bytes =
+ * window position (ky*3+kx) of the first maximum; the backward routes dy by that index without re-reading x. */
+int mvit_maxpool_skip_fwd_idx(const float* x, float* y, void* idx, int B, int T, int H, int W, int C, void* stream);
+int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
+
 /* Stem backward: dW [96][3][3][7][7], dpos_spatial, dpos_temporal accumulated from dx [B][N][96] (the input clip
  * needs no gradient; the bias gradient is mvit_colsum). */
 int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,

@@ -217,6 +217,31 @@ def test_maxpool_skip_bwd(hip_lib, B, T, H, W, C):
     xd, dyd = x.detach().to(DEV), dy.to(DEV)
     _hip.check(hip_lib.mvit_maxpool_skip_bwd(_hip.ptr(xd), _hip.ptr(dyd), _hip.ptr(dx), B, T, H, W, C, _st()))
     _close(dx, x.grad, 1e-6)
+    # training pair: forward records the first-maximum position, backward routes dy by it
+    y2 = torch.empty(B, Lo, C, device=DEV)
+    idx = torch.empty(B, Lo, C, dtype=torch.uint8, device=DEV)
+    dx2 = torch.empty_like(dx)
+    _hip.check(hip_lib.mvit_maxpool_skip_fwd_idx(_hip.ptr(xd), _hip.ptr(y2), _hip.ptr(idx), B, T, H, W, C, _st()))
+    _hip.check(hip_lib.mvit_maxpool_skip_bwd_idx(_hip.ptr(idx), _hip.ptr(dyd), _hip.ptr(dx2), B, T, H, W, C, _st()))
+    assert torch.equal(y2.cpu(), y.detach().reshape(B, C, Lo).transpose(1, 2))
+    _close(dx2, x.grad, 1e-6)
+
+
+def test_maxpool_skip_idx_ties_go_to_the_first_maximum(hip_lib):
+    B, T, H, W, C = 1, 2, 9, 7, 8
+    x = torch.randint(0, 3, (B, T * H * W, C), generator=torch.Generator().manual_seed(9)).float().requires_grad_(True)
+    t = x.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+    y = F.max_pool3d(t, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    Lo = y.shape[2] * y.shape[3] * y.shape[4]
+    dy = _rnd(B, Lo, C, seed=24)
+    y.reshape(B, C, Lo).transpose(1, 2).backward(dy)
+    xd, dyd = x.detach().to(DEV), dy.to(DEV)
+    y2 = torch.empty(B, Lo, C, device=DEV)
+    idx = torch.empty(B, Lo, C, dtype=torch.uint8, device=DEV)
+    dx2 = torch.empty(B, T * H * W, C, device=DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_fwd_idx(_hip.ptr(xd), _hip.ptr(y2), _hip.ptr(idx), B, T, H, W, C, _st()))
+    _hip.check(hip_lib.mvit_maxpool_skip_bwd_idx(_hip.ptr(idx), _hip.ptr(dyd), _hip.ptr(dx2), B, T, H, W, C, _st()))
+    _close(dx2, x.grad, 1e-6)
 
 
 @pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56)])
