@@ -99,26 +99,44 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out[j] (+)= sum_b part[b][j]   -- block = 64 columns x 4 part-slices, LDS combine
+// out[j] (+)= sum_b part[b][j]   -- block = 64 columns x 4 part-slices, LDS combine; blockIdx.y slices the partial rows and
+// the slices meet in fp32 atomics (outputs pre-zeroed by the launcher unless accumulating).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
                                                               float* __restrict__ out_a, float* __restrict__ out_b,
                                                               int split, int accumulate) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + col;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
     float s = 0.f;
     if (j < width)
-        for (int b = sl; b < nparts; b += 4) s += part[(int64_t)b * width + j];
+        for (int b = b0 + sl; b < b1; b += 4) s += part[(int64_t)b * width + j];
     red[sl][col] = s;
     __syncthreads();
     if (sl == 0 && j < width) {
         s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         float* o = (j < split) ? out_a + j : out_b + (j - split);
-        *o = accumulate ? *o + s : s;
+        if (gridDim.y > 1) atomicAdd(o, s);
+        else *o = accumulate ? *o + s : s;
     }
 }
 
-#define LN_BWD_MAXBLK 256
+static int launch_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
+                                  hipStream_t st) {
+    int slices = nparts / 64;
+    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+    if (slices > 1 && !accumulate) {
+        if (hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)(split < width ? split : width), st) != hipSuccess) return MVIT_ELAUNCH;
+        if (width > split && hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)(width - split), st) != hipSuccess) return MVIT_ELAUNCH;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
+                       accumulate);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+#define LN_BWD_MAXBLK 1024     // 4 workgroups per CU: the kernel is HBM-bound
 extern "C" int64_t mvit_layernorm_bwd_workspace_bytes(int C) { return (int64_t)LN_BWD_MAXBLK * 2 * C * sizeof(float); }
 
 template <int C, typename TDY>
@@ -130,10 +148,7 @@ static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int
     hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
                        dx, acc, ws, rows, eps);
     MVIT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, ws, (int)blocks, 2 * C, dgamma,
-                       dbeta, C, acc_param);
-    MVIT_LAUNCH_CHECK();
-    return MVIT_OK;
+    return launch_reduce_partials(ws, (int)blocks, 2 * C, dgamma, dbeta, C, acc_param, st);
 }
 
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
