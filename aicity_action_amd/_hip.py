@@ -55,6 +55,7 @@ _SIGS = {
     "mvit_maxpool_skip_fwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_bwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "mvit_stem_bwd2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_ln_partial": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mvit_head_project_train": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -143,7 +143,7 @@ class _StemFn(torch.autograd.Function):
         dW = torch.zeros(96, 3, 3, 7, 7, dtype=torch.float32, device=dev)
         dps = torch.zeros_like(m.pos_embed_spatial)
         dpt = torch.zeros_like(m.pos_embed_temporal)
-        _hip.check(hx.L.mvit_stem_bwd(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, _st()),
+        _hip.check(hx.L.mvit_stem_bwd2(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act, _st()),
                    "stem_bwd")
         db = hx.colsum(dx.view(-1, 96))
         return None, dW, db, dps, dpt, None

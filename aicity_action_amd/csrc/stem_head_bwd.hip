@@ -80,6 +80,137 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stem weight gradient on the matrix cores (16-bit path):  dW[c][ci,dt,dy,dx] = sum_tok dxg[tok][c] * in[ci][2t-1+dt][4y-3+dy][4x-3+dx]
+// as a GEMM whose contraction runs over the tokens of one output row (b, t, y).  Workgroup = 3 waves (wave = dt) working
+// for one input channel ci; per output row it stages
+//   * the row's token gradients [So][96] as a 16-bit row-major tile (A operand by transposing reads), and
+//   * the 3 x 7 input rows it needs as "dx planes"  P[dt][dy][dx][x] = in[4x-3+dx]  (each fp32 pixel goes to one or two
+//     planes), so that the B fragment of 8 consecutive tokens for one (dy,dx) column is one aligned 16-byte read;
+//     plane rows are 240 B apart -> the 16 lanes of a ds_read_b128 hit 16 distinct 16-B slots.
+// Columns: k-block kb (0,1), lane column j -> dy = 4kb + (j>>3), dx = j&7; dy = 7 / dx = 7 are zero padding.
+// Accumulators (3 c-blocks x 2 k-blocks per wave) live across all rows of the persistent workgroup; one fp32 atomic per
+// element at the end.
+// ------------------------------------------------------------------------------------------------
+#define SW_XS 120                       // plane row stride in elements (240 B)
+#define SW_PLANE (8 * SW_XS)            // one (dt,dy): 8 dx rows
+#define SW_PBYTES (3 * 7 * SW_PLANE * 2)    // 40320
+#define SW_DROWB 192
+#define SW_DBYTES (112 * SW_DROWB)          // 21504
+typedef __attribute__((address_space(3))) bf16x4 sw_lds_b4;
+
+__global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __restrict__ clip, const float* __restrict__ dxg,
+                                                              float* __restrict__ dW, int B, int T, int S, int To, int So) {
+    __shared__ __attribute__((aligned(16))) char smem[SW_PBYTES + SW_DBYTES];
+    bf16_t* sP = reinterpret_cast<bf16_t*>(smem);
+    char* sD = smem + SW_PBYTES;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = blockIdx.x % 3;
+    const int nks = (So + 15) / 16;
+    for (int i = tid; i < (SW_PBYTES + SW_DBYTES) / 16; i += 192) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][kb][i] = 0.f;
+
+    // fragment addressing
+    const int i16 = lane & 15, gi = lane >> 4;
+    const int a_lane = (8 * h + (i16 >> 2)) * SW_DROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;     // + ks*16 rows, + cb*64 B
+    int b_lane[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int dy = 4 * kb + (r >> 3), dx = r & 7;
+        b_ok[kb] = dy < 7 && dx < 7;
+        b_lane[kb] = ((wave * 7 + (dy < 7 ? dy : 0)) * SW_PLANE + dx * SW_XS + 8 * h) * 2;    // + ks*16 elements
+    }
+
+    const int nrows = B * To * So;        // output rows (b, to, yo)
+    const int nwg = gridDim.x / 3;
+    const int x4 = S / 4;                 // float4 groups per input row == So
+    for (int row = blockIdx.x / 3; row < nrows; row += nwg) {
+        const int yo = row % So;
+        const int to = (row / So) % To;
+        const int b = row / (So * To);
+        __syncthreads();                  // everyone is done with the previous row's tiles
+        // ---- token gradients of the row -> 16-bit [So][96] ----------------------------------------
+        const float* drow = dxg + (int64_t)row * So * 96;
+        for (int i = tid; i < So * 12; i += 192) {
+            const int tok = i / 12, c8 = i - tok * 12;
+            float4 lo, hi;
+            load8(drow + tok * 96 + 8 * c8, lo, hi);
+            uint4 o;
+            o.x = pack_bf16x2(lo.x, lo.y); o.y = pack_bf16x2(lo.z, lo.w); o.z = pack_bf16x2(hi.x, hi.y); o.w = pack_bf16x2(hi.z, hi.w);
+            *reinterpret_cast<uint4*>(sD + tok * SW_DROWB + c8 * 16) = o;
+        }
+        // ---- input rows -> dx planes -----------------------------------------------------------------
+        for (int i = tid; i < 21 * x4; i += 192) {
+            const int pr = i / x4, xq = i - pr * x4;        // plane row (dt*7+dy), float4 group x' of the input row
+            const int dt = pr / 7, dy = pr - dt * 7;
+            const int ti = 2 * to + dt - 1, yi = 4 * yo + dy - 3;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ti >= 0 && ti < T && yi >= 0 && yi < S)
+                v = load4(clip + ((((int64_t)b * 3 + ci) * T + ti) * S + yi) * S + 4 * xq);
+            bf16_t* pl = sP + pr * SW_PLANE;
+            // in[4x'+p]: plane dx = p+3 at x = x'; plane dx = p-1 at x = x'+1 (p >= 1)
+            pl[3 * SW_XS + xq] = f32_to_bf16(v.x);
+            pl[4 * SW_XS + xq] = f32_to_bf16(v.y);
+            pl[5 * SW_XS + xq] = f32_to_bf16(v.z);
+            pl[6 * SW_XS + xq] = f32_to_bf16(v.w);
+            if (xq + 1 < So) {
+                pl[0 * SW_XS + xq + 1] = f32_to_bf16(v.y);
+                pl[1 * SW_XS + xq + 1] = f32_to_bf16(v.z);
+                pl[2 * SW_XS + xq + 1] = f32_to_bf16(v.w);
+            }
+        }
+        __syncthreads();
+        const int ti_w = 2 * to + wave - 1;
+        if (ti_w < 0 || ti_w >= T) continue;          // this wave's temporal tap reads padding only (uniform per wave)
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 af[3], bf[2];
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const char* ap = sD + a_lane + ks * 16 * SW_DROWB + cb * 64;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(ap));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(ap + 4 * SW_DROWB));
+                af[cb][0] = lo[0]; af[cb][1] = lo[1]; af[cb][2] = lo[2]; af[cb][3] = lo[3];
+                af[cb][4] = hi[0]; af[cb][5] = hi[1]; af[cb][6] = hi[2]; af[cb][7] = hi[3];
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf[kb] = *reinterpret_cast<const bf16x8*>(smem + b_lane[kb] + ks * 32);
+                if (!b_ok[kb]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[kb][e] = 0;
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) acc[cb][kb] = mfma16(af[cb], bf[kb], acc[cb][kb]);
+        }
+    }
+    // D[c][k]: row c = 32cb + (i&3) + 8(i>>2) + 4h, column k = lane&31 -> (dy, dx)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int dy = 4 * kb + (r >> 3), dx = r & 7;
+        if (dy < 7 && dx < 7) {
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 32 * cb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    atomicAdd(dW + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx, acc[cb][kb][i]);
+                }
+        }
+    }
+}
+
 // dpos_s[hw][c] = sum_{b,t} dx[b][t][hw][c] ;  dpos_t[t][c] = sum_{b,hw} dx[b][t][hw][c]  (the latter via fp32 atomics
 // on T*96 outputs after a block-level partial sum)
 __global__ __launch_bounds__(256) void stem_pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dps,
@@ -121,6 +252,27 @@ extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, floa
     const int ntiles = B * To * tiles_x * tiles_y;
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, st, clip, dx, dW, B, T, S, To, So,
                        tiles_x, tiles_y);
+    MVIT_LAUNCH_CHECK();
+    dim3 grid((So * So + 7) / 8, To);
+    hipLaunchKernelGGL(stem_pos_bwd_kernel, grid, dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// act_dtype selects the weight-gradient kernel: MVIT_F32 -> exact fp32 VALU kernel, MVIT_BF16 -> matrix-core kernel on
+// 16-bit copies of the clip rows and token gradients (fp32 accumulation).  Positional-embedding gradients are fp32 sums.
+extern "C" int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
+                              int B, int T, int S, int act_dtype, void* stream) {
+    if (act_dtype == MVIT_F32) return mvit_stem_bwd(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, stream);
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (!clip || !dx || !dW || !dpos_spatial || !dpos_temporal || B <= 0 || T <= 0 || S <= 0) return MVIT_EINVAL;
+    if ((T & 1) || (S & 3)) return MVIT_EUNSUPPORTED;
+    const int To = T / 2, So = S / 4;
+    if (So > 112) return mvit_stem_bwd(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, stream);
+    hipStream_t st = as_stream(stream);
+    const int64_t nrows = (int64_t)B * To * So;
+    int nwg = (int)(nrows < 170 ? nrows : 170);          // x3 input channels = 510 workgroups (2 per CU by LDS)
+    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(3 * nwg), dim3(192), 0, st, clip, dx, dW, B, T, S, To, So);
     MVIT_LAUNCH_CHECK();
     dim3 grid((So * So + 7) / 8, To);
     hipLaunchKernelGGL(stem_pos_bwd_kernel, grid, dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So);

@@ -168,6 +168,10 @@ int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float* dx, int B
  * needs no gradient; the bias gradient is mvit_colsum). */
 int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
                   int T, int S, void* stream);
+/* Same, with the kernel family chosen by act_dtype (MVIT_F32: exact fp32 VALU; MVIT_BF16: matrix-core weight gradient on
+ * 16-bit operands, fp32 accumulate). */
+int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
+                   int T, int S, int act_dtype, void* stream);
 
 /* Head, training variant.  mvit_head_ln_partial = stage 1 of mvit_head_fwd (workspace [B][ceil(N/32)][C]);
  * mvit_head_project_train: z = mean * mask (dropout mask holding 0 or 1/(1-p), or NULL), logits = z W^T + b;

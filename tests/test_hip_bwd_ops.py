@@ -244,7 +244,7 @@ def test_maxpool_skip_idx_ties_go_to_the_first_maximum(hip_lib):
     _close(dx2, x.grad, 1e-6)
 
 
-@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56)])
+@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 2, 448)])
 def test_stem_bwd(hip_lib, B, T, S):
     clip = _rnd(B, 3, T, S, S, seed=25)
     w = _rnd(96, 3, 3, 7, 7, seed=26, scale=0.05).requires_grad_(True)
@@ -262,6 +262,15 @@ def test_stem_bwd(hip_lib, B, T, S):
     _close(dW, w.grad.reshape(96, 441), 3e-5)
     _close(dps, ps.grad[0], 2e-5)
     _close(dpt, pt.grad[0], 2e-5)
+    # matrix-core weight gradient: same sums over 16-bit roundings of the clip and of the token gradients
+    w2 = w.detach().clone().requires_grad_(True)
+    x2 = F.conv3d(clip.to(torch.bfloat16).float(), w2, None, stride=(2, 4, 4), padding=(1, 3, 3)).flatten(2).transpose(1, 2)
+    x2.backward(dx.to(torch.bfloat16).float())
+    dW2 = torch.zeros(96, 441, device=DEV)
+    dps2, dpt2 = torch.zeros(So * So, 96, device=DEV), torch.zeros(To, 96, device=DEV)
+    _hip.check(hip_lib.mvit_stem_bwd2(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW2), _hip.ptr(dps2), _hip.ptr(dpt2), B, T, S, _hip.BF16, _st()))
+    _close(dW2, w2.grad.reshape(96, 441), 3e-5)
+    _close(dps2, ps.grad[0], 2e-5)
 
 
 def test_head_train_and_bwd(hip_lib):
