@@ -30,6 +30,23 @@ class _Ctx(object):
         self.L = model._lib()
         self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
         self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
+        self._zpool, self._zoff = None, 0
+
+    def zeros(self, *shape):
+        """fp32 zeros carved from ONE zero-filled buffer per step (the ~290 small gradient buffers of a backward pass
+        would otherwise cost a fill launch each); 256-byte aligned views."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64
+        if self._zpool is None or self._zoff + n_al > self._zpool.numel():
+            total = sum((p.numel() + 63) // 64 * 64 for p in self.m.parameters())
+            dev = next(self.m.parameters()).device
+            self._zpool = torch.zeros(max(total, n_al), dtype=torch.float32, device=dev)
+            self._zoff = 0
+        t = self._zpool[self._zoff:self._zoff + n].view(*shape)
+        self._zoff += n_al
+        return t
 
     def w(self, p):
         return self.m._w(p, self.act)
@@ -65,8 +82,8 @@ class _Ctx(object):
 
     def wgrad(self, a, dy, N, K, row_scale=None, rps=0):
         """(dW, db): weight gradient and the fused bias gradient (column sums of the scaled dy)."""
-        dW = torch.zeros(N, K, dtype=torch.float32, device=a.device)
-        db = torch.zeros(N, dtype=torch.float32, device=a.device)
+        dW = self.zeros(N, K)
+        db = self.zeros(N)
         adt = _hip.F32 if a.dtype == torch.float32 else _hip.BF16
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
@@ -140,9 +157,9 @@ class _StemFn(torch.autograd.Function):
         dx = dx.contiguous()
         B, _, T, S, _ = clip.shape
         dev = clip.device
-        dW = torch.zeros(96, 3, 3, 7, 7, dtype=torch.float32, device=dev)
-        dps = torch.zeros_like(m.pos_embed_spatial)
-        dpt = torch.zeros_like(m.pos_embed_temporal)
+        dW = hx.zeros(96, 3, 3, 7, 7)
+        dps = hx.zeros(*m.pos_embed_spatial.shape)
+        dpt = hx.zeros(*m.pos_embed_temporal.shape)
         _hip.check(hx.L.mvit_stem_bwd2(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act, _st()),
                    "stem_bwd")
         db = hx.colsum(dx.view(-1, 96))
@@ -246,7 +263,7 @@ class _BlockFn(torch.autograd.Function):
                                                             (dk, at.pool_k, at.norm_k, g.stride_kv[1]),
                                                             (dv, at.pool_v, at.norm_v, g.stride_kv[1]))):
             dconv = torch.empty_like(dbuf)
-            dw = torch.zeros(96, 1, 3, 3, 3, dtype=torch.float32, device=dev)
+            dw = hx.zeros(96, 1, 3, 3, 3)
             dgm = torch.empty(96, dtype=torch.float32, device=dev)
             dbt = torch.empty(96, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_pool_conv_ln_bwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
