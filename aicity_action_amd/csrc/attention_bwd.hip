@@ -71,19 +71,43 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------
 // pass A (bf16 MFMA): dQ.   grid (ceil(Lq/128), B*heads), 4 waves x 32 queries.
 // ------------------------------------------------------------------------------------------------
+// K and V tiles arrive as in the forward kernel: a 3-stage LDS ring of (K image | V image) filled by
+// global_load_lds_dwordx4 with the rotation swizzle on the source address (two tiles in flight, one s_barrier per tile).
+// The K image serves both the row reads (S^T = K Q^T) and the transposing reads (dQ^T += K^T dS^T): the latter apply the
+// row's rotation to their own address and are issued as inline asm (no compiler vmcnt(0) in front of them).
+typedef __attribute__((address_space(1))) const void b_gptr_t;
+typedef __attribute__((address_space(3))) void b_lptr_t;
+#define BQ_STAGES 3
+#define BQ_TILEB (2 * B_T * B_ROWB)      // 24 KiB
+
+template <int OFF>
+__device__ __forceinline__ bf16x4 b_tr16(uint32_t addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ bf16x8 b_join(bf16x4 lo, bf16x4 hi) {
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+#define B_WAIT6(A, N) \
+    asm volatile("s_waitcnt lgkmcnt(%12)" \
+                 : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]), "+v"(A[9]), \
+                   "+v"(A[10]), "+v"(A[11]) \
+                 : "n"(N))
+
 template <bool ADD_Q>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
-                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
-                                                          float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * B_T * B_ROWB];
-    char* sK = smem;                       // rotation image of K (row reads)
-    char* sKp = smem + B_T * B_ROWB;       // plain image of K (transposed reads)
-    char* sV = smem + 2 * B_T * B_ROWB;    // rotation image of V (row reads)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+                                                             const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                             const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
+                                                             float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // BQ_STAGES x (K rotation image | V rotation image)
     const int bh = blockIdx.y;
     const int b = bh / heads, g = bh - b * heads;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     int qi = blockIdx.x * 128 + wave * 32 + r;
     const bool q_ok = qi < Lq;
@@ -93,35 +117,57 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
     const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
     const bf16_t* dOrow = dO + ((int64_t)b * Lq + qi) * C + g * 96;
+
+    // DMA pieces: LDS position p = 64*piece + lane holds chunk (p%12 - rot(row)) of row p/12 (K and V alike)
+    uint32_t g_off[3];
+    int p_row[3], p_c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = 64 * (3 * wave + i) + lane;
+        const int row = p / 12, pos = p - row * 12;
+        int c = pos - ((row >> 2) & 3);
+        c = c < 0 ? c + 12 : c;
+        p_row[i] = row; p_c[i] = c;
+        g_off[i] = (uint32_t)(row * 12 + c) * 16u;
+    }
+    auto dma = [&](int k0, int stage) {
+        const char* kt_base = reinterpret_cast<const char*>(Kb) + (int64_t)k0 * B_ROWB;
+        const char* vt_base = reinterpret_cast<const char*>(Vb) + (int64_t)k0 * B_ROWB;
+        char* dst = smem + stage * BQ_TILEB + 1024 * (3 * wave);
+        if (k0 + B_T <= Lk) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_global_load_lds((b_gptr_t*)(kt_base + g_off[i]), (b_lptr_t*)(dst + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((b_gptr_t*)(vt_base + g_off[i]), (b_lptr_t*)(dst + B_T * B_ROWB + 1024 * i), 16, 0, 0);
+            }
+        } else {        // tail tile: rows past Lk re-read the last valid row (finite; their P is masked to 0 below)
+            const int last = Lk - 1 - k0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = p_row[i] < last ? p_row[i] : last;
+                const uint32_t o = (uint32_t)(row * 12 + p_c[i]) * 16u;
+                __builtin_amdgcn_global_load_lds((b_gptr_t*)(kt_base + o), (b_lptr_t*)(dst + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((b_gptr_t*)(vt_base + o), (b_lptr_t*)(dst + B_T * B_ROWB + 1024 * i), 16, 0, 0);
+            }
+        }
+    };
+    const int nkt = (Lk + B_T - 1) / B_T;
+    dma(0, 0);
+    if (nkt > 1) dma(B_T, 1);
+
     bf16x8 qf[6], dof[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
         qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
         dof[ks] = *reinterpret_cast<const bf16x8*>(dOrow + 16 * ks + 8 * h);
     }
-    const float lse = LSE[(int64_t)bh * Lq + qi];
-    const float dlt = delta[(int64_t)bh * Lq + qi];
+    float lse = LSE[(int64_t)bh * Lq + qi];
+    float dlt = delta[(int64_t)bh * Lq + qi];
+    // consume the register operands once: their vmcnt wait is paid here, not inside the loop
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+    asm volatile("" : "+v"(lse), "+v"(dlt));
 
-    int s_row[3], s_chk[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = tid + 256 * i;
-        s_row[i] = c / 12;
-        s_chk[i] = c - s_row[i] * 12;
-    }
-    uint4 rk[3], rv[3];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int key = k0 + s_row[i];
-            rk[i] = make_uint4(0, 0, 0, 0);
-            rv[i] = rk[i];
-            if (key < Lk) {
-                rk[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * 96 + 8 * s_chk[i]);
-                rv[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * 96 + 8 * s_chk[i]);
-            }
-        }
-    };
     int koff[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
@@ -129,8 +175,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         p = p >= 12 ? p - 12 : p;
         koff[ks] = p * 16;
     }
+    // transposing reads on the rotation image: row 16*s16 + 4h + (i16>>2) (+8 for the second half), rotation h (+2)
     const int i16 = lane & 15, gi = lane >> 4;
-    const int t_lane = (4 * h + (i16 >> 2)) * B_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t t_lo[3], t_hi[3];
+#pragma unroll
+    for (int db = 0; db < 3; ++db) {
+        const int c = 4 * db + 2 * (gi & 1) + ((i16 & 3) >> 1);
+        int pl = c + h, ph = c + ((h + 2) & 3);
+        pl = pl >= 12 ? pl - 12 : pl;
+        ph = ph >= 12 ? ph - 12 : ph;
+        t_lo[db] = lds0 + (4 * h + (i16 >> 2)) * B_ROWB + 16 * pl + 8 * (i16 & 1);
+        t_hi[db] = lds0 + (4 * h + (i16 >> 2) + 8) * B_ROWB + 16 * ph + 8 * (i16 & 1);
+    }
 
     f32x16 dq[3];
 #pragma unroll
@@ -138,33 +195,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
-    const int nkt = (Lk + B_T - 1) / B_T;
-    gload(0);
+    int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<uint4*>(sK + rot_off(s_row[i], s_chk[i])) = rk[i];
-            *reinterpret_cast<uint4*>(sKp + s_row[i] * B_ROWB + s_chk[i] * 16) = rk[i];
-            *reinterpret_cast<uint4*>(sV + rot_off(s_row[i], s_chk[i])) = rv[i];
-        }
-        __syncthreads();
-        if (kt + 1 < nkt) gload((kt + 1) * B_T);
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) dma((kt + 2) * B_T, stage == 0 ? 2 : stage - 1);
+        const char* sK = smem + stage * BQ_TILEB;
+        const char* sV = sK + B_T * B_ROWB;
+        const uint32_t so = (uint32_t)(stage * BQ_TILEB);
+        stage = stage == BQ_STAGES - 1 ? 0 : stage + 1;
+
         f32x16 s[2], dp[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
-            const char* kr = sK + (32 * kb + r) * B_ROWB;
-            const char* vr = sV + (32 * kb + r) * B_ROWB;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + koff[ks]);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vr + koff[ks]);
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * B_ROWB + koff[ks]);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (32 * kb + r) * B_ROWB + koff[ks]);
                 s[kb] = mfma16(kf, qf[ks], s[kb]);      // S^T  = K . Q^T
                 dp[kb] = mfma16(vf, dof[ks], dp[kb]);   // dP^T = V . dO^T
             }
-        }
+        // K^T fragments of the first two 16-key steps: requested now, they land under the dS arithmetic
+        bf16x4 ta[12];
+#define TRQ(A, S16) \
+        A[0] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[0] + so); A[1] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[0] + so); \
+        A[2] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[1] + so); A[3] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[1] + so); \
+        A[4] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[2] + so); A[5] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[2] + so); \
+        A[6] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[0] + so); A[7] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[0] + so); \
+        A[8] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[1] + so); A[9] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[1] + so); \
+        A[10] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[2] + so); A[11] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[2] + so);
+        TRQ(ta, 0)
         const int kbase = kt * B_T;
         const bool tail = kbase + B_T > Lk;
         bf16x8 dsf[4];
@@ -186,13 +251,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                 dsf[2 * kb + sh] = pack8(dsv);
             }
         // dQ^T += K^T . dS^T
+        bf16x4 tb[12];
+        B_WAIT6(ta, 0);
+        TRQ(tb, 2)
 #pragma unroll
-        for (int s16 = 0; s16 < 4; ++s16)
+        for (int s16 = 0; s16 < 2; ++s16)
 #pragma unroll
-            for (int db = 0; db < 3; ++db) {
-                const bf16x8 kf = tr_frag(sKp + t_lane + s16 * 16 * B_ROWB + db * 64);
-                dq[db] = mfma16(kf, dsf[s16], dq[db]);
-            }
+            for (int db = 0; db < 3; ++db) dq[db] = mfma16(b_join(ta[6 * s16 + 2 * db], ta[6 * s16 + 2 * db + 1]), dsf[s16], dq[db]);
+        __builtin_amdgcn_sched_barrier(0);
+        B_WAIT6(tb, 0);
+#pragma unroll
+        for (int s16 = 0; s16 < 2; ++s16)
+#pragma unroll
+            for (int db = 0; db < 3; ++db) dq[db] = mfma16(b_join(tb[6 * s16 + 2 * db], tb[6 * s16 + 2 * db + 1]), dsf[2 + s16], dq[db]);
+#undef TRQ
     }
     if (q_ok) {
         bf16_t* orow = dQ + ((int64_t)bh * Lq + qi) * 96;
@@ -566,11 +638,18 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
                            (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
         MVIT_LAUNCH_CHECK();
         dim3 gq((Lq + 127) / 128, B * heads);
+        static bool dq_attr_done = false;
+        if (!dq_attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess)
+                return MVIT_ELAUNCH;
+            dq_attr_done = true;
+        }
         if (add_q)
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
         else
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
         MVIT_LAUNCH_CHECK();
         const int nz = dkv_splits(B, heads, Lq, Lk);
