@@ -43,11 +43,12 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
                                                             float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A_STAGES x (K image 12 KiB | V image 12 KiB)
 
-    const int bh = blockIdx.y;            // b*heads + g
+    int qtile, bh;                        // bh = b*heads + g
+    xcd_group_map(qtile, bh);
     const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * A_QB + wave * A_QW;
+    const int q0 = qtile * A_QB + wave * A_QW;
 
     const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
     const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
@@ -248,9 +249,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     }
 #ifdef ATT_STAMP
     if (LSE && lane == 0) {
-        for (int i = 0; i < 6; ++i) LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + i] = (float)tacc[i] / nkt;
-        LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + 6] = (float)(__builtin_readcyclecounter() - t_begin);
-        LSE[(int64_t)bh * Lq + blockIdx.x * A_QB + wave * 8 + 7] = (float)(wall_clock64() - w_begin);
+        for (int i = 0; i < 6; ++i) LSE[(int64_t)bh * Lq + qtile * A_QB + wave * 8 + i] = (float)tacc[i] / nkt;
+        LSE[(int64_t)bh * Lq + qtile * A_QB + wave * 8 + 6] = (float)(__builtin_readcyclecounter() - t_begin);
+        LSE[(int64_t)bh * Lq + qtile * A_QB + wave * 8 + 7] = (float)(wall_clock64() - w_begin);
         return;
     }
 #endif

@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                              bf16_t* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
                                                              float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // BQ_STAGES x (K rotation image | V rotation image)
-    const int bh = blockIdx.y;
+    int qtile, bh;
+    xcd_group_map(qtile, bh);
     const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    int qi = blockIdx.x * 128 + wave * 32 + r;
+    int qi = qtile * 128 + wave * 32 + r;
     const bool q_ok = qi < Lq;
     qi = q_ok ? qi : Lq - 1;
     const int C = heads * 96;
@@ -302,11 +303,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     char* sD = smem + 2 * B_T * B_ROWB;     // dO rotation image
     char* sDp = smem + 3 * B_T * B_ROWB;    // dO plain image
     float* sL = reinterpret_cast<float*>(smem + 4 * B_T * B_ROWB);   // lse[64], delta[64]
-    const int bh = blockIdx.y;
+    int ktile, bh;
+    xcd_group_map(ktile, bh);
     const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    int ki = blockIdx.x * 128 + wave * 32 + r;
+    int ki = ktile * 128 + wave * 32 + r;
     const bool k_ok = ki < Lk;
     ki = k_ok ? ki : Lk - 1;
     const int C = heads * 96;

@@ -120,4 +120,21 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 }
 
+// XCD-aware (tile, group) mapping for grids with x = tiles of one group and y = groups that share an operand (the K/V of one
+// (batch, head), ...).  Workgroups are dispatched round-robin over the 8 XCDs in linear-id order (x fastest), so with the
+// identity mapping the tiles of one group land on all 8 L2s and every L2 has to hold every group's operand; here each XCD gets
+// whole groups, so a group's operand is fetched into ONE L2 and hit there by all its tiles.
+__device__ __forceinline__ void xcd_group_map(int& tile, int& group) {
+    const int nt = gridDim.x, ng = gridDim.y;
+    tile = blockIdx.x;
+    group = blockIdx.y;
+    if ((ng & 7) == 0) {
+        const int lin = blockIdx.y * nt + blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3;
+        const int gq = slot / nt;
+        group = gq * 8 + xcd;
+        tile = slot - gq * nt;
+    }
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
