@@ -185,15 +185,28 @@ def main():
                 del do, dq, dk, dv, ws
             del q, k, v, o, lse
 
-        def rl(name, tot_flops, tot_ms, per_block):
+        def pmc_traffic(fname, key):
+            """HBM bytes per launch from the committed PMC measurement of this exact workload (tools/traffic.sh: rocprofv3 --pmc
+            FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None for any other configuration."""
+            path = os.path.join(ROOT, "profiles", fname)
+            if not (args.batch == 8 and args.crop == 448 and args.precision == "bf16" and os.path.exists(path)):
+                return None
+            try:
+                return round(float(json.load(open(path))[key]), 0)
+            except Exception:
+                return None
+
+        def rl(name, tot_flops, tot_ms, per_block, traffic=None):
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
-        fwd_rl = rl("attn_fwd_%s_kernel" % sfx, sum(flops), fwd_ms, per_f)
+        fwd_rl = rl("attn_fwd_%s_kernel" % sfx, sum(flops), fwd_ms, per_f,
+                    pmc_traffic("r1_attn_fwd_hbm_traffic.json", "traffic_bytes_per_launch"))
         if train:
-            roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b)
+            roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b,
+                          pmc_traffic("r1_attn_bwd_hbm_traffic.json", "traffic_bytes_per_call"))
             extra_rooflines["roofline_attention_fwd"] = fwd_rl
         else:
             roofline = fwd_rl
