@@ -107,7 +107,8 @@ def _defaults():
                  "Q_POOL_RESIDUAL": False, "Q_POOL_ALL": False, "CHANNEL_EXPAND_FRONT": False,
                  "POOL_SKIP_USE_CONV": False, "NO_NORM_BEFORE_AVG": False},
         "DATA": {"NUM_FRAMES": 8, "SAMPLING_RATE": 8, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256,
-                 "INPUT_CHANNEL_NUM": [3, 3], "MEAN": [0.45, 0.45, 0.45], "STD": [0.225, 0.225, 0.225]},
+                 "INPUT_CHANNEL_NUM": [3, 3], "MEAN": [0.45, 0.45, 0.45], "STD": [0.225, 0.225, 0.225],
+                 "MULTI_LABEL": False, "ENSEMBLE_METHOD": "sum"},
         "CONTRA": {"ENABLE": False},
         "DETECTION": {"ENABLE": False, "USE_CUBE_PROP": False, "USE_SPATIAL_MAXPOOL_BEFORE_PROJ": False},
         "SOLVER": {"BASE_LR": 0.1, "LR_POLICY": "cosine", "COSINE_END_LR": 0.0, "MAX_EPOCH": 300,
@@ -116,7 +117,7 @@ def _defaults():
                    "OPTIMIZING_METHOD": "sgd", "BASE_LR_SCALE_NUM_SHARDS": False,
                    "COSINE_AFTER_WARMUP": False, "ZERO_WD_1D_PARAM": False, "CLIP_GRAD_VAL": None,
                    "CLIP_GRAD_L2NORM": None},
-        "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "OUTPUT_DIR": "./tmp", "RNG_SEED": 1,
+        "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "OUTPUT_DIR": "./tmp", "RNG_SEED": 1, "LOG_PERIOD": 100,
         "DIST_BACKEND": "nccl",
         # build-specific knob (not in the reference): arithmetic of the HIP path, "bf16" or "fp32"
         "HIP": {"PRECISION": "bf16"},

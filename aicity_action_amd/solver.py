@@ -126,20 +126,53 @@ class HipAdamW(object):
         _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
                                      self.eps, self.step_count, st), "adamw")
         self.last_grad_norm = self._out2      # device tensor [norm, coef]; no host sync here
+        # the kernel wrote the parameters behind torch's back: bump their version counters so every version-keyed cache (the
+        # 16-bit / transposed GEMM weight copies of MViT._w and autograd._Ctx.wt) is refreshed on the next use
+        bump = torch.autograd.graph.increment_version
+        for grp in self.groups:
+            for p in grp["params"]:
+                bump(p)
         return self._out2
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr,
-                "state": {n: (self.state[p][0], self.state[p][1]) for grp in self.groups for n, p in zip(grp["names"], grp["params"])}}
+        """``torch.optim.AdamW.state_dict()`` layout (what the reference writes into ``optimizer_state`` of a .pyth checkpoint,
+        slowfast/utils/checkpoint.py:127-134): parameters indexed in group order [decay..., no-decay...] -- the order
+        ``construct_optimizer`` builds them in (optimizer.py:140-206) -- so the two optimizers' checkpoints interchange."""
+        state, groups, idx = {}, [], 0
+        for grp in self.groups:
+            ids = []
+            for p in grp["params"]:
+                m, v = self.state[p]
+                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": grp["weight_decay"], "amsgrad": False,
+                           "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                           "params": ids})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.lr = sd["lr"]
+        if "param_groups" not in sd:           # layout of the first revision of this class: {"step", "lr", "state": {name: (m, v)}}
+            self.step_count = sd["step"]
+            self.lr = sd["lr"]
+            for grp in self.groups:
+                for n, p in zip(grp["names"], grp["params"]):
+                    m, v = sd["state"][n]
+                    self.state[p][0].copy_(m)
+                    self.state[p][1].copy_(v)
+            return
+        idx = 0
+        assert sum(len(g["params"]) for g in sd["param_groups"]) == sum(len(g["params"]) for g in self.groups), \
+            "optimizer state has a different number of parameters"
+        self.lr = float(sd["param_groups"][0]["lr"])
         for grp in self.groups:
-            for n, p in zip(grp["names"], grp["params"]):
-                m, v = sd["state"][n]
-                self.state[p][0].copy_(m)
-                self.state[p][1].copy_(v)
+            for p in grp["params"]:
+                ent = sd["state"].get(idx)
+                if ent is not None:            # torch omits entries of parameters that never received a gradient
+                    self.state[p][0].copy_(ent["exp_avg"])
+                    self.state[p][1].copy_(ent["exp_avg_sq"])
+                    self.step_count = int(float(ent["step"]))
+                idx += 1
 
 
 def construct_optimizer(model, cfg):

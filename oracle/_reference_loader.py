@@ -62,6 +62,23 @@ class _CfgNode(dict):
         return json.dumps(self, default=str)
 
 
+def _simplejson_dumps(obj, sort_keys=False, use_decimal=True, **kw):
+    """Stand-in for simplejson.dumps (third party, absent here): as published, ``use_decimal`` serialises decimal.Decimal as a
+    bare number literal with the Decimal's own digits (str(d)); everything else as the stdlib encoder does."""
+    import decimal
+
+    def enc(o):
+        if isinstance(o, decimal.Decimal):
+            return str(o)
+        if isinstance(o, dict):
+            items = sorted(o.items()) if sort_keys else o.items()
+            return "{" + ", ".join(json.dumps(str(k)) + ": " + enc(v) for k, v in items) + "}"
+        if isinstance(o, (list, tuple)):
+            return "[" + ", ".join(enc(v) for v in o) + "]"
+        return json.dumps(o)
+    return enc(obj)
+
+
 def _install_stubs():
     def mod(name, **attrs):
         m = sys.modules.get(name)
@@ -100,7 +117,7 @@ def _install_stubs():
             return _PM()
 
     mod("iopath.common.file_io", PathManagerFactory=_PMF, g_pathmgr=_PM())
-    mod("simplejson", dumps=json.dumps, loads=json.loads)
+    mod("simplejson", dumps=_simplejson_dumps, loads=json.loads)
     mod("detectron2")
     mod("detectron2.layers", ROIAlign=object)
 

@@ -1,0 +1,150 @@
+"""GPU: the train / eval / test loops of aicity_action_amd/engine.py driving the HIP model end to end (tiny config):
+epoch driver with checkpoint + auto-resume reproduces the uninterrupted run, json_stats lines, view-sum test ensemble."""
+import json
+import logging
+
+import pytest
+import torch
+
+from conftest import cfg_for_case, load_golden
+
+from aicity_action_amd import engine
+from aicity_action_amd.models import build_model
+from aicity_action_amd.solver import construct_optimizer
+from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+
+pytestmark = pytest.mark.gpu
+
+
+class _Loader(list):
+    """Stand-in for the reference's DataLoader: len() + iteration over (inputs, labels, index, meta)."""
+
+
+def _batches(meta, n, seed0, ncls):
+    out = _Loader()
+    for i in range(n):
+        clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], seed0 + i)
+        labels = torch.tensor([(3 * i + j) % ncls for j in range(meta["batch"])])
+        out.append(([clip], labels, torch.arange(meta["batch"]) + i * meta["batch"], {}))
+    return out
+
+
+def _make(meta, precision, outdir):
+    cfg = cfg_for_case(meta, precision, train=True)
+    cfg.NUM_GPUS = 1
+    cfg.MVIT.DROPPATH_RATE = 0.0            # deterministic runs: no drop-path / dropout draws
+    cfg.MODEL.DROPOUT_RATE = 0.0
+    cfg.SOLVER.MAX_EPOCH, cfg.SOLVER.WARMUP_EPOCHS = 2, 1.0
+    cfg.TRAIN.CHECKPOINT_PERIOD, cfg.TRAIN.EVAL_PERIOD, cfg.LOG_PERIOD = 1, 1, 1
+    cfg.OUTPUT_DIR = outdir
+    cfg.TRAIN.AUTO_RESUME = True
+    model = build_model(cfg)
+    load_synth_weights(model, meta["weight_seed"])
+    return cfg, model
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_driver_checkpoints_and_resumes(tmp_path, precision, caplog):
+    _, meta = load_golden("tiny_even")
+    ncls = meta.get("num_classes", 18)
+    train_loader = _batches(meta, 3, 100, ncls)
+    val_loader = _batches(meta, 2, 200, ncls)
+    # (a) uninterrupted: 2 epochs
+    cfg_a, model_a = _make(meta, precision, str(tmp_path / "a"))
+    with caplog.at_level(logging.INFO, logger="aicity_action_amd.engine"):
+        res = engine.train(cfg_a, model_a, train_loader, val_loader)
+    assert [e for e, _ in res] == [0, 1] and all(0.0 <= r <= 100.0 for _, r in res)
+    lines = [json.loads(r.message.split("json_stats: ")[1]) for r in caplog.records if r.message.startswith("json_stats: ")]
+    kinds = [l["_type"] for l in lines]
+    assert kinds == ["train_iter"] * 3 + ["train_epoch"] + ["val_iter"] * 2 + ["val_epoch"] + ["train_iter"] * 3 + ["train_epoch"] + \
+        ["val_iter"] * 2 + ["val_epoch"]
+    assert lines[0]["epoch"] == "1/2" and lines[0]["iter"] == "1/3" and lines[4]["iter"] == "1/2"
+    assert lines[0]["lr"] == pytest.approx(cfg_a.SOLVER.WARMUP_START_LR, abs=1e-5)
+    assert engine.has_checkpoint(cfg_a.OUTPUT_DIR) and engine.get_last_checkpoint(cfg_a.OUTPUT_DIR).endswith("checkpoint_epoch_00002.pyth")
+    # (b) one epoch, checkpoint, then a fresh model whose state must come entirely from the file
+    cfg_b, model_b = _make(meta, precision, str(tmp_path / "b"))
+    opt_b = construct_optimizer(model_b, cfg_b)
+    engine.train_epoch(train_loader, model_b, opt_b, None, engine.TrainMeter(len(train_loader), cfg_b), 0, cfg_b)
+    engine.save_checkpoint(cfg_b.OUTPUT_DIR, model_b, opt_b, 0, cfg_b)
+    cfg_c, model_c = _make(meta, precision, str(tmp_path / "b"))
+    for p in model_c.parameters():
+        p.data.zero_()
+    opt_c = construct_optimizer(model_c, cfg_c)
+    assert engine.load_train_checkpoint(cfg_c, model_c, opt_c) == 1
+    ck = torch.load(engine.get_last_checkpoint(cfg_c.OUTPUT_DIR), map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == ["cfg", "epoch", "model_state", "optimizer_state"] and ck["epoch"] == 0
+    assert len(ck["model_state"]) == 350 or len(ck["model_state"]) == len(model_c.state_dict())
+    assert sorted(ck["optimizer_state"].keys()) == ["param_groups", "state"] and len(ck["optimizer_state"]["param_groups"]) == 2
+    for (k, a), b in zip(model_b.state_dict().items(), model_c.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
+def test_resume_reproduces_uninterrupted_run(tmp_path):
+    _, meta = load_golden("tiny_even")
+    train_loader = _batches(meta, 3, 100, 18)
+    cfg_a, model_a = _make(meta, "fp32", str(tmp_path / "a"))
+    engine.train(cfg_a, model_a, train_loader, None)
+    # same schedule (MAX_EPOCH 2), stopped after epoch 0 by deleting the later checkpoint and resuming in a fresh model
+    cfg_b, model_b = _make(meta, "fp32", str(tmp_path / "b"))
+    opt_b = construct_optimizer(model_b, cfg_b)
+    tm = engine.TrainMeter(len(train_loader), cfg_b)
+    engine.train_epoch(train_loader, model_b, opt_b, None, tm, 0, cfg_b)
+    engine.save_checkpoint(cfg_b.OUTPUT_DIR, model_b, opt_b, 0, cfg_b)
+    cfg_c, model_c = _make(meta, "fp32", str(tmp_path / "b"))
+    engine.train(cfg_c, model_c, train_loader, None)            # auto-resumes at epoch 1
+    # Adam turns the rounding noise of (mathematically) zero gradients -- e.g. key biases, which softmax cancels -- into +-lr
+    # steps, and the fp32 atomics make that noise run-dependent: compare what the model computes, and the bulk of the weights
+    big, tot = 0, 0
+    for (k, a), b in zip(model_a.state_dict().items(), model_c.state_dict().values()):
+        big += int(((a - b).abs() > 1e-4).sum())
+        tot += a.numel()
+    assert big <= 0.01 * tot, (big, tot)
+    probe = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], 999).cuda()
+    with torch.no_grad():
+        pa, pc = model_a.eval()([probe]), model_c.eval()([probe])
+    assert (pa - pc).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_weight_copies_follow_the_fused_optimizer(tmp_path, precision):
+    """The AdamW kernel writes parameters through raw pointers; the cached 16-bit / transposed GEMM weight copies must be
+    rebuilt afterwards (regression: they were keyed on a version counter the kernel did not bump)."""
+    _, meta = load_golden("tiny_even")
+    loader = _batches(meta, 2, 100, 18)
+    cfg, model = _make(meta, precision, str(tmp_path))
+    opt = construct_optimizer(model, cfg)
+    engine.train_epoch(loader, model, opt, None, engine.TrainMeter(len(loader), cfg), 0, cfg)
+    cfg2, fresh = _make(meta, precision, str(tmp_path))
+    fresh.load_state_dict(model.state_dict())
+    clip = loader[0][0][0].cuda()
+    labels = loader[0][1].cuda()
+    outs = []
+    for m in (model, fresh):
+        m.train()
+        logits = m([clip])
+        loss = engine._loss(cfg, logits, labels)
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        outs.append((logits.detach(), torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()))
+    assert torch.equal(outs[0][0], outs[1][0])                              # forward sees the stepped weights
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[1][1]                # and so does the backward (transposed copies)
+
+
+def test_perform_test_view_sum(tmp_path):
+    _, meta = load_golden("tiny_even")
+    cfg, model = _make(meta, "bf16", str(tmp_path))
+    B = meta["batch"]
+    # 2 "videos" x B clips each (num_clips = B): the loader yields one video's clips per iteration
+    loader = _Loader()
+    for v in range(2):
+        clip = synth_clip(B, meta["num_frames"], meta["crop"], 300 + v)
+        loader.append(([clip], torch.full((B,), v + 1), torch.arange(B) + v * B, {}))
+    tm = engine.TestMeter(num_videos=2, num_clips=B, num_cls=cfg.MODEL.NUM_CLASSES, overall_iters=len(loader))
+    stats = engine.perform_test(loader, model, tm, cfg)
+    assert stats["split"] == "test_final" and set(stats) == {"split", "top1_acc", "top5_acc"}
+    assert tm.clip_count.tolist() == [B, B]
+    with torch.no_grad():
+        ref = model.eval()([loader[0][0][0].cuda()]).float().cpu().sum(0)
+    assert torch.allclose(tm.video_preds[0], ref, atol=1e-5)
+    assert torch.allclose(tm.video_preds.sum(1), torch.full((2,), float(B)), atol=1e-3)      # softmax scores summed over views
