@@ -49,22 +49,11 @@ class _Ctx(object):
         return t
 
     def w(self, p):
-        return self.m._w(p, self.act)
+        return self.m._w_pair(p, self.act)[0]
 
     def wt(self, p):
         """[K][N] transposed copy in the activation dtype (operand of the data-gradient GEMM)."""
-        cache = self.m._bf16_cache
-        key = ("t", id(p))
-        ent = cache.get(key)
-        if ent is None or ent[0] != p._version or ent[1].device != p.device:
-            t = p.detach().t().contiguous()
-            if self.act == _hip.BF16:
-                buf = torch.empty(t.shape, dtype=self.adt, device=p.device)
-                _hip.check(self.L.mvit_cast_f32_to_bf16(_hip.ptr(t), _hip.ptr(buf), t.numel(), _st()), "cast")
-                t = buf
-            ent = (p._version, t)
-            cache[key] = ent
-        return ent[1]
+        return self.m._w_pair(p, self.act)[1]
 
     # y = a . w^T (+bias)(gelu)(*row_scale)(+residual)
     def linear(self, a, w, bias, out_dtype, residual=None, gelu=False, row_scale=None, rps=0):

@@ -314,6 +314,37 @@ extern "C" int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t r
     return MVIT_OK;
 }
 
+// fp32 [R][C] -> 16-bit copy [R][C] (optional) and 16-bit TRANSPOSED copy [C][R] in one pass (GEMM weights after an
+// optimizer step: the forward reads W, the data-gradient GEMM reads W^T).  64x64 tiles through LDS, both outputs coalesced.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, bf16_t* __restrict__ dt,
+                                                             int R, int C) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16_t v = 0;
+        if (r < R && c < C) {
+            v = f32_to_bf16(s[(int64_t)r * C + c]);
+            if (d) d[(int64_t)r * C + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) dt[(int64_t)c * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int rows, int cols, void* stream) {
+    if (!src || !dst_t || rows <= 0 || cols <= 0) return MVIT_EINVAL;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, as_stream(stream), src, (bf16_t*)dst,
+                       (bf16_t*)dst_t, rows, cols);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 #ifdef MVIT_HALF_IS_FP16
 extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: fp16)"; }
 #else

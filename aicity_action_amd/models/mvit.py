@@ -195,6 +195,24 @@ class MViT(nn.Module):
             self._bf16_cache[key] = ent
         return ent[1]
 
+    def _w_pair(self, param, act):
+        """(W, W^T) of a 2-D GEMM weight in the activation dtype, produced together by one kernel and cached per parameter
+        version (training: the forward reads W, the data-gradient GEMM W^T)."""
+        key = ("pair", self.precision, id(param))
+        ent = self._bf16_cache.get(key)
+        if ent is None or ent[0] != param._version or ent[1].device != param.device:
+            if act == _hip.F32:
+                ent = (param._version, param, param.detach().t().contiguous())
+            else:
+                R, C = param.shape
+                w = torch.empty(R, C, dtype=self._half_dtype(), device=param.device)
+                wt = torch.empty(C, R, dtype=self._half_dtype(), device=param.device)
+                st = torch.cuda.current_stream().cuda_stream
+                _hip.check(self._lib().mvit_cast_transpose_f32_to_bf16(_hip.ptr(param), _hip.ptr(w), _hip.ptr(wt), R, C, st), "cast_t")
+                ent = (param._version, w, wt)
+            self._bf16_cache[key] = ent
+        return ent[1], ent[2]
+
     def forward(self, x, bboxes=None, dataset_name=None, run_cross_proj=False, use_moco=False, moco_momentum=0.9,
                 return_logits=False):
         if not self.direct_input:

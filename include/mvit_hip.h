@@ -212,6 +212,10 @@ int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols, const float* row_scale,
                                int64_t rows_per_scale, void* stream);
 
+/* dst[r][c] (optional, may be NULL) and dst_t[c][r] = (16-bit) src[r][c]: the forward and the data-gradient GEMM operands of one
+ * nn.Linear weight (attention.py:231,281, common.py:27-31 and their backward), refreshed together after an optimizer step. */
+int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

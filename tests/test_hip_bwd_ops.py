@@ -355,3 +355,17 @@ def test_grad_norm_and_adamw_match_torch(hip_lib):
         _hip.check(hip_lib.mvit_adamw_step(_hip.ptr(table), len(rec), _hip.ptr(out2), 1e-3, 0.9, 0.999, 1e-8, step, _st()))
         for p, r in zip(dp, ref_p):
             _close(p, r.detach(), 2e-6)
+
+
+@pytest.mark.parametrize("R,C", [(96, 96), (288, 96), (100, 70), (1152, 384)])
+def test_cast_transpose(hip_lib, R, C):
+    x = _rnd(R, C, seed=41)
+    xd = x.to(DEV)
+    d = torch.empty(R, C, dtype=torch.bfloat16, device=DEV)
+    dt = torch.empty(C, R, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_cast_transpose_f32_to_bf16(_hip.ptr(xd), _hip.ptr(d), _hip.ptr(dt), R, C, _st()))
+    ref = x.to(torch.bfloat16)
+    assert torch.equal(d.cpu(), ref) and torch.equal(dt.cpu(), ref.t().contiguous())
+    dt2 = torch.zeros_like(dt)
+    _hip.check(hip_lib.mvit_cast_transpose_f32_to_bf16(_hip.ptr(xd), None, _hip.ptr(dt2), R, C, _st()))
+    assert torch.equal(dt2.cpu(), ref.t().contiguous())
