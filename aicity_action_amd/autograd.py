@@ -118,10 +118,11 @@ class _Ctx(object):
 
 def _block_params(blk, g):
     at = blk.attn
-    ps = [blk.norm1.weight, blk.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
-          at.pool_q.weight, at.norm_q.weight, at.norm_q.bias, at.pool_k.weight, at.norm_k.weight, at.norm_k.bias,
-          at.pool_v.weight, at.norm_v.weight, at.norm_v.bias, blk.norm2.weight, blk.norm2.bias,
-          blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+    ps = [blk.norm1.weight, blk.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias]
+    if g.kernel_q:
+        ps += [at.pool_q.weight, at.norm_q.weight, at.norm_q.bias]
+    ps += [at.pool_k.weight, at.norm_k.weight, at.norm_k.bias, at.pool_v.weight, at.norm_v.weight, at.norm_v.bias,
+           blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
     if g.expand:
         ps += [blk.proj_max_pool.weight, blk.proj_max_pool.bias]
     return ps
@@ -172,9 +173,12 @@ class _BlockFn(torch.autograd.Function):
         q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
         k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
         v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        for which, (buf, conv, norm, stride) in enumerate(((q, at.pool_q, at.norm_q, g.stride_q[1]),
-                                                           (k, at.pool_k, at.norm_k, g.stride_kv[1]),
-                                                           (v, at.pool_v, at.norm_v, g.stride_kv[1]))):
+        pools = [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
+        if g.kernel_q:
+            pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
+        else:
+            _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, _st()), "head_split")
+        for which, buf, conv, norm, stride in pools:
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
                                                _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W, stride, norm.eps, act, _st()),
                        "pool")
@@ -245,12 +249,15 @@ class _BlockFn(torch.autograd.Function):
                    "attention_bwd")
         del d_o
         d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)
-        pws = _ws(max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1]),
+        pws = _ws(max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1] if g.stride_q else 1),
                       L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1])), dev)
         pool_grads = []
-        for which, (dbuf, conv, norm, stride) in enumerate(((dq, at.pool_q, at.norm_q, g.stride_q[1]),
-                                                            (dk, at.pool_k, at.norm_k, g.stride_kv[1]),
-                                                            (dv, at.pool_v, at.norm_v, g.stride_kv[1]))):
+        bpools = [(1, dk, at.pool_k, at.norm_k, g.stride_kv[1]), (2, dv, at.pool_v, at.norm_v, g.stride_kv[1])]
+        if g.kernel_q:
+            bpools.insert(0, (0, dq, at.pool_q, at.norm_q, g.stride_q[1]))
+        else:
+            _hip.check(L.mvit_head_split_bwd(_hip.ptr(dq), _hip.ptr(d_qkv), 3 * Cout, 0, B, h, N, act, _st()), "head_split_bwd")
+        for which, dbuf, conv, norm, stride in bpools:
             dconv = torch.empty_like(dbuf)
             dw = hx.zeros(96, 1, 3, 3, 3)
             dgm = torch.empty(96, dtype=torch.float32, device=dev)

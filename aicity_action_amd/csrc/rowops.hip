@@ -345,6 +345,55 @@ extern "C" int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void
     return MVIT_OK;
 }
 
+// Head split without pooling (blocks whose query has no pooling conv: MVIT.Q_POOL_ALL off, attention.py:14-15,239-246):
+// out[b][g][n][d] = qkv[b][n][chan_off + g*96 + d]; the backward writes the gradient back into the fused slice.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void head_split_kernel(T* __restrict__ qkv, int64_t ld, int chan_off, T* __restrict__ hs, int B, int heads,
+                                                         int64_t N) {
+    constexpr int CW = 16 / sizeof(T);          // elements per 16-byte access
+    constexpr int CPR = 96 / CW;                // accesses per 96-channel head row
+    const int64_t total = (int64_t)B * heads * N * CPR;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CPR);
+        int64_t rem = i / CPR;
+        const int64_t n = rem % N; rem /= N;
+        const int g = (int)(rem % heads);
+        const int64_t b = rem / heads;
+        T* pq = qkv + (b * N + n) * ld + chan_off + g * 96 + c * CW;
+        T* ph = hs + i * CW;
+        if (BWD) *reinterpret_cast<uint4*>(pq) = *reinterpret_cast<const uint4*>(ph);
+        else *reinterpret_cast<uint4*>(ph) = *reinterpret_cast<const uint4*>(pq);
+    }
+}
+
+template <bool BWD>
+static int launch_head_split(void* qkv, int64_t ld, int chan_off, void* hs, int B, int heads, int64_t N, int act_dtype, void* stream) {
+    if (!qkv || !hs || B <= 0 || heads <= 0 || N <= 0) return MVIT_EINVAL;
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if ((ld & 7) || (chan_off & 7)) return MVIT_EUNSUPPORTED;
+    const int64_t total = (int64_t)B * heads * N * (act_dtype == MVIT_F32 ? 24 : 12);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (act_dtype == MVIT_F32)
+        hipLaunchKernelGGL((head_split_kernel<float, BWD>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (float*)qkv, ld, chan_off,
+                           (float*)hs, B, heads, N);
+    else
+        hipLaunchKernelGGL((head_split_kernel<bf16_t, BWD>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (bf16_t*)qkv, ld,
+                           chan_off, (bf16_t*)hs, B, heads, N);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+extern "C" int mvit_head_split_fwd(const void* qkv, int64_t ld, int chan_off, void* out, int B, int heads, int64_t N, int act_dtype,
+                                   void* stream) {
+    return launch_head_split<false>(const_cast<void*>(qkv), ld, chan_off, out, B, heads, N, act_dtype, stream);
+}
+
+extern "C" int mvit_head_split_bwd(const void* dout, void* dqkv, int64_t ld, int chan_off, int B, int heads, int64_t N, int act_dtype,
+                                   void* stream) {
+    return launch_head_split<true>(dqkv, ld, chan_off, const_cast<void*>(dout), B, heads, N, act_dtype, stream);
+}
+
 #ifdef MVIT_HALF_IS_FP16
 extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: fp16)"; }
 #else

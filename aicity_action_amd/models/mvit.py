@@ -131,10 +131,10 @@ class MViT(nn.Module):
             _unsupported(g.head_dim != 96, "head_dim %d (kernels are specialised for 96)" % g.head_dim)
             _unsupported(bool(g.kernel_q) and tuple(g.kernel_q) != (3, 3, 3), "q pool kernel != 3x3x3")
             _unsupported(bool(g.kernel_kv) and tuple(g.kernel_kv) != (3, 3, 3), "kv pool kernel != 3x3x3")
-            _unsupported(not g.kernel_q or not g.kernel_kv, "blocks without q/kv pooling conv (Q_POOL_ALL off)")
+            _unsupported(not g.kernel_kv, "blocks without a k/v pooling conv")
             for st in (g.stride_q, g.stride_kv):
-                _unsupported(st[0] != 1 or st[1] != st[2], "pool stride %s" % (st,))
-            _unsupported(g.stride_q[1] not in (1, 2), "q stride %s" % (g.stride_q,))
+                _unsupported(bool(st) and (st[0] != 1 or st[1] != st[2]), "pool stride %s" % (st,))
+            _unsupported(bool(g.stride_q) and g.stride_q[1] not in (1, 2), "q stride %s" % (g.stride_q,))
         self.geoms = geoms
 
         embed_dim = mv.EMBED_DIM
@@ -301,9 +301,12 @@ class MViT(nn.Module):
         q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
         k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
         v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        for which, (buf, conv, norm, stride) in enumerate(((q, at.pool_q, at.norm_q, g.stride_q[1]),
-                                                           (k, at.pool_k, at.norm_k, g.stride_kv[1]),
-                                                           (v, at.pool_v, at.norm_v, g.stride_kv[1]))):
+        pools = [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
+        if g.kernel_q:
+            pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
+        else:       # pool_q is None (Q_POOL_ALL off): the query is the head-split slice itself, no LayerNorm (attention.py:14-15)
+            _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, st), "head_split")
+        for which, buf, conv, norm, stride in pools:
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight),
                                                _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W,
                                                stride, norm.eps, act, st), "pool%d" % which)

@@ -212,6 +212,12 @@ int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols, const float* row_scale,
                                int64_t rows_per_scale, void* stream);
 
+/* Query path of blocks WITHOUT a pooling conv (MVIT.Q_POOL_ALL off -> pool_q is None, attention.py:14-15,131-134,239-246):
+ * out[b][g][n][:] = qkv[b][n][chan_off + g*96 : +96] (head split only, no LayerNorm); _bwd copies dout back into the slice of the
+ * fused gradient buffer. */
+int mvit_head_split_fwd(const void* qkv, int64_t ld, int chan_off, void* out, int B, int heads, int64_t N, int act_dtype, void* stream);
+int mvit_head_split_bwd(const void* dout, void* dqkv, int64_t ld, int chan_off, int B, int heads, int64_t N, int act_dtype, void* stream);
+
 /* dst[r][c] (optional, may be NULL) and dst_t[c][r] = (16-bit) src[r][c]: the forward and the data-gradient GEMM operands of one
  * nn.Linear weight (attention.py:231,281, common.py:27-31 and their backward), refreshed together after an optimizer step. */
 int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int rows, int cols, void* stream);

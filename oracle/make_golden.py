@@ -42,6 +42,8 @@ CASES = {
     # name: (yaml, overrides, batch, clip seed)
     "tiny_even": ("MVITV2_FULL_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 64, "DATA.TEST_CROP_SIZE": 64}), 2, 11),
     "tiny_odd": ("MVITV2_FULL_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 56, "DATA.TEST_CROP_SIZE": 56}), 3, 12),
+    # non-FULL variant (Q_POOL_ALL / Q_POOL_RESIDUAL off): blocks 0 and 2 have no q pooling conv (pool_q None) and no "+q"
+    "tiny_plain": ("MVITV2_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 64, "DATA.TEST_CROP_SIZE": 64}), 2, 13),
     "full224": ("MVITV2_FULL_B_16x4_CONV.yaml", {}, 1, 1),
     "full448": ("MVITV2_FULL_B_16x4_CONV_448.yaml", {}, 1, 2),
 }

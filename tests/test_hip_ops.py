@@ -236,3 +236,17 @@ def test_head(hip_lib, B, N, C):
                                      18, 1e-6, _st()))
     _close(logits, ref_logits, 1e-5)
     _close(probs, ref_logits.softmax(1), 1e-5)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+def test_head_split_round_trip(hip_lib, act):
+    B, h, N = 2, 3, 77
+    C = 96 * h
+    qkv = _act(_rnd(B, N, 3 * C, seed=51), act).to(DEV)
+    out = torch.empty(B, h, N, 96, dtype=qkv.dtype, device=DEV)
+    _hip.check(hip_lib.mvit_head_split_fwd(_hip.ptr(qkv), 3 * C, C, _hip.ptr(out), B, h, N, act, _st()))
+    ref = qkv[:, :, C:2 * C].reshape(B, N, h, 96).permute(0, 2, 1, 3)
+    assert torch.equal(out, ref.contiguous())
+    back = torch.zeros_like(qkv)
+    _hip.check(hip_lib.mvit_head_split_bwd(_hip.ptr(out), _hip.ptr(back), 3 * C, C, B, h, N, act, _st()))
+    assert torch.equal(back[:, :, C:2 * C], qkv[:, :, C:2 * C]) and float(back[:, :, :C].abs().max()) == 0.0

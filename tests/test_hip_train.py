@@ -24,7 +24,7 @@ def _setup(name, precision):
     return z, meta, cfg, model, clip, labels
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain"])
 def test_fp32_train_step_matches_reference_golden(name):
     z, meta, cfg, model, clip, labels = _setup(name, "fp32")
     decay, no_decay = param_groups(model, cfg)
@@ -54,7 +54,7 @@ def test_fp32_train_step_matches_reference_golden(name):
     print("[%s fp32] worst relative grad error %.2e" % (name, worst))
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain"])
 def test_bf16_train_step_is_close_to_reference(name):
     z, meta, cfg, model, clip, labels = _setup(name, "bf16")
     logits = model([clip])

@@ -24,7 +24,7 @@ def _run(name, train=False):
     return z, meta, cfg, sd, clip
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "full224"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224"])
 def test_oracle_forward_matches_reference_golden(name):
     z, meta, cfg, sd, clip = _run(name)
     taps = {}
@@ -40,7 +40,7 @@ def test_oracle_forward_matches_reference_golden(name):
         assert list(taps[k]) == list(z[k])
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain"])
 def test_oracle_train_step_matches_reference_golden(name):
     z, meta, cfg, sd, clip = _run(name, train=True)
     sd = {k: v.requires_grad_(True) for k, v in sd.items()}
