@@ -341,7 +341,14 @@ def forward_train(model, clip):
             keep = 1.0 - g.drop_path                       # common.py:46-59: one draw per sample per call
             dp1 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
             dp2 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
-        x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
+        if model.use_act_checkpoint and torch.is_grad_enabled():
+            # MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037, attention.py checkpoint.checkpoint(blk, x, thw)): keep only
+            # the block input, run the block's forward again inside backward.  The drop-path draws are made here, outside.
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(lambda xx, g=g, blk=blk, dp1=dp1, dp2=dp2: _BlockFn.apply(xx, hx, g, blk, dp1, dp2, *_block_params(blk, g)),
+                           x, use_reentrant=False)
+        else:
+            x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
     mask = None
     if model.training and model.head_dropout > 0.0:
         p = model.head_dropout                             # head_helper.py:410-411

@@ -527,7 +527,11 @@ def perform_test(test_loader, model, test_meter, cfg):
 def train(cfg, model, train_loader, val_loader=None, optimizer=None, scaler=None):
     """Epoch driver (train_net.py:612-800): resume, per-epoch train / checkpoint / eval in the reference's order."""
     optimizer = optimizer if optimizer is not None else solver.construct_optimizer(model, cfg)
-    start_epoch = load_train_checkpoint(cfg, model, optimizer, scaler)
+    if scaler is None:
+        # train_net.py:634: GradScaler(enabled=cfg.TRAIN.MIXED_PRECISION); only the fp16 arithmetic needs the loss scale
+        fp16 = getattr(getattr(cfg, "HIP", None), "PRECISION", "bf16") == "fp16"
+        scaler = solver.HipGradScaler(enabled=bool(cfg.TRAIN.MIXED_PRECISION) and fp16)
+    start_epoch = load_train_checkpoint(cfg, model, optimizer, scaler if scaler.is_enabled() else None)
     train_meter = TrainMeter(len(train_loader), cfg)
     val_meter = ValMeter(len(val_loader), cfg) if val_loader is not None else None
     if du.get_rank() == 0:
@@ -542,7 +546,7 @@ def train(cfg, model, train_loader, val_loader=None, optimizer=None, scaler=None
         if du.get_rank() == 0:
             logger.info("Epoch {} takes {:.2f}s.".format(cur_epoch + 1, time.perf_counter() - t0))
         if is_checkpoint_epoch(cfg, cur_epoch):
-            save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch, cfg, scaler)
+            save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, cur_epoch, cfg, scaler if scaler.is_enabled() else None)
         if val_meter is not None and is_eval_epoch(cfg, cur_epoch):
             results.append((cur_epoch, eval_epoch(val_loader, model, val_meter, cur_epoch, cfg)))
     return results

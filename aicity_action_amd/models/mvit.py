@@ -106,7 +106,7 @@ class MViT(nn.Module):
         _unsupported(cfg.DETECTION.ENABLE, "DETECTION.ENABLE")
         _unsupported(cfg.MODEL.USE_MULTI_HEAD, "MODEL.USE_MULTI_HEAD")
         _unsupported(cfg.CONTRA.ENABLE, "CONTRA.ENABLE")
-        _unsupported(cfg.MODEL.ACT_CHECKPOINT, "MODEL.ACT_CHECKPOINT")
+        self.use_act_checkpoint = bool(cfg.MODEL.ACT_CHECKPOINT)     # video_model_builder.py:1036-1037
         _unsupported(list(mv.PATCH_KERNEL) != [3, 7, 7] or list(mv.PATCH_STRIDE) != [2, 4, 4]
                      or list(mv.PATCH_PADDING) != [1, 3, 3], "a patch embed other than k(3,7,7) s(2,4,4) p(1,3,3)")
         if mv.NORM != "layernorm":
@@ -220,9 +220,7 @@ class MViT(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("MViT (HIP path) needs its input on a gfx950 device; there is no CPU fallback")
         if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            if self.precision == "fp16":
-                raise NotImplementedError("HIP.PRECISION fp16 is inference-only (no loss scaling in the training path); "
-                                          "train with bf16 or fp32")
+            # fp16 training needs loss scaling: solver.HipGradScaler (engine.train enables it for TRAIN.MIXED_PRECISION)
             # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
             return forward_with_grad(self, x, return_logits)

@@ -111,8 +111,10 @@ class HipAdamW(object):
         self._out2 = torch.empty(2, dtype=torch.float32, device=dev)
         self._grad_ptrs = ptrs
 
-    def step(self, max_norm=None):
-        """One clipped AdamW step.  max_norm None -> cfg.SOLVER.CLIP_GRAD_L2NORM (None/0 disables clipping)."""
+    def step(self, max_norm=None, grad_scale=None):
+        """One clipped AdamW step.  max_norm None -> cfg.SOLVER.CLIP_GRAD_L2NORM (None/0 disables clipping).
+        grad_scale (float): the gradients carry this loss-scale factor (HipGradScaler): they are unscaled inside the fused
+        update, the clip acts on the unscaled norm, and the step is SKIPPED (returns None) when the norm is inf / nan."""
         cur = [p.grad.data_ptr() if p.grad is not None else 0 for grp in self.groups for p in grp["params"]]
         if self._table is None or cur != self._grad_ptrs:
             self._build()                                   # grads were re-allocated (e.g. set_to_none): refresh the table
@@ -121,8 +123,20 @@ class HipAdamW(object):
         L = _hip.lib()
         st = torch.cuda.current_stream().cuda_stream
         self.step_count += 1
-        _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, float(max_norm), _hip.ptr(self._partials),
-                                    _hip.ptr(self._out2), st), "grad_norm")
+        if grad_scale is not None:
+            _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, 0.0, _hip.ptr(self._partials), _hip.ptr(self._out2), st),
+                       "grad_norm")
+            norm = self._out2[0] / grad_scale                       # unscaled global norm (inf / nan on overflow)
+            if not bool(torch.isfinite(norm)):                      # the one host sync torch's GradScaler.step also makes
+                self.step_count -= 1
+                self.last_grad_norm = self._out2
+                return None
+            coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0) if max_norm else torch.ones_like(norm)
+            self._out2[0] = norm
+            self._out2[1] = coef / grad_scale                       # clip and unscale in the kernel's single gradient factor
+        else:
+            _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, float(max_norm), _hip.ptr(self._partials),
+                                        _hip.ptr(self._out2), st), "grad_norm")
         _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
                                      self.eps, self.step_count, st), "adamw")
         self.last_grad_norm = self._out2      # device tensor [norm, coef]; no host sync here
@@ -173,6 +187,62 @@ class HipAdamW(object):
                     self.state[p][1].copy_(ent["exp_avg_sq"])
                     self.step_count = int(float(ent["step"]))
                 idx += 1
+
+
+class HipGradScaler(object):
+    """Dynamic loss scaling for fp16 training, the role ``torch.cuda.amp.GradScaler`` plays in the reference's loop
+    (tools/train_net.py:126,231-246): ``scale(loss).backward(); step(optimizer); update()``.  Unscaling, the inf / nan check and
+    the global-norm clip are folded into ``HipAdamW.step(grad_scale=...)``; ``state_dict`` uses GradScaler's keys so the
+    ``scaler_state`` entry of a .pyth checkpoint interchanges."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self._enabled = bool(enabled)
+        self._scale = float(init_scale)
+        self._growth_factor, self._backoff_factor, self._growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._growth_tracker = 0
+        self._skipped = False
+
+    def is_enabled(self):
+        return self._enabled
+
+    def get_scale(self):
+        return self._scale if self._enabled else 1.0
+
+    def scale(self, loss):
+        return loss * self._scale if self._enabled else loss
+
+    def step(self, optimizer, max_norm=None):
+        if not self._enabled:
+            return optimizer.step(max_norm)
+        out = optimizer.step(max_norm, grad_scale=self._scale)
+        self._skipped = out is None
+        return out
+
+    def update(self):
+        if not self._enabled:
+            return
+        if self._skipped:
+            self._scale *= self._backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self._growth_interval:
+                self._scale *= self._growth_factor
+                self._growth_tracker = 0
+        self._skipped = False
+
+    def state_dict(self):
+        if not self._enabled:
+            return {}
+        return {"scale": self._scale, "growth_factor": self._growth_factor, "backoff_factor": self._backoff_factor,
+                "growth_interval": self._growth_interval, "_growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, sd):
+        if not self._enabled or not sd:
+            return
+        self._scale = float(sd["scale"])
+        self._growth_factor, self._backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self._growth_interval, self._growth_tracker = int(sd["growth_interval"]), int(sd["_growth_tracker"])
 
 
 def construct_optimizer(model, cfg):

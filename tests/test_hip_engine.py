@@ -148,3 +148,61 @@ def test_perform_test_view_sum(tmp_path):
         ref = model.eval()([loader[0][0][0].cuda()]).float().cpu().sum(0)
     assert torch.allclose(tm.video_preds[0], ref, atol=1e-5)
     assert torch.allclose(tm.video_preds.sum(1), torch.full((2,), float(B)), atol=1e-3)      # softmax scores summed over views
+
+
+def _grads_for(meta, precision, tmp, clip, labels, act_ckpt=False, scale=None):
+    cfg, model = _make(meta, precision, tmp)
+    cfg.MODEL.ACT_CHECKPOINT = act_ckpt
+    if act_ckpt:
+        cfg2, model = _make(meta, precision, tmp)
+        model.use_act_checkpoint = True
+    model.train()
+    logits = model([clip])
+    loss = engine._loss(cfg, logits, labels)
+    (loss * scale if scale else loss).backward()
+    return model, loss.item(), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+
+
+def test_activation_checkpointing_gives_the_same_gradients(tmp_path):
+    """MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037): block forwards are re-run inside backward."""
+    _, meta = load_golden("tiny_even")
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], 5).cuda()
+    labels = torch.tensor([1, 7]).cuda()
+    _, l0, g0 = _grads_for(meta, "fp32", str(tmp_path), clip, labels)
+    _, l1, g1 = _grads_for(meta, "fp32", str(tmp_path), clip, labels, act_ckpt=True)
+    assert abs(l0 - l1) <= 1e-6
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * max(1.0, g0[k].abs().max().item()), k
+
+
+def test_fp16_training_with_loss_scaler(tmp_path):
+    """TRAIN.MIXED_PRECISION semantics (train_net.py:126,231-246) on the fp16 build: scaled backward, unscale + inf check + clip
+    in the fused optimizer step, skipped step and scale back-off on overflow, GradScaler-compatible state."""
+    from aicity_action_amd.solver import HipGradScaler
+    _, meta = load_golden("tiny_even")
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], 5).cuda()
+    labels = torch.tensor([1, 7]).cuda()
+    # gradients of the fp16 path (scale 1024, unscaled on the host here) point the same way as the fp32 ones
+    _, l32, g32 = _grads_for(meta, "fp32", str(tmp_path), clip, labels)
+    _, l16, g16 = _grads_for(meta, "fp16", str(tmp_path), clip, labels, scale=1024.0)
+    assert abs(l32 - l16) <= 2e-2
+    a = torch.cat([g32[k].flatten() for k in g32]).double()
+    b = torch.cat([g16[k].flatten() for k in g32]).double() / 1024.0
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos >= 0.999 and abs(float(b.norm() / a.norm()) - 1.0) <= 0.02, (cos, float(b.norm() / a.norm()))
+    # loop with the scaler: an absurd initial scale overflows -> step skipped, scale halves; then steps go through
+    cfg, model = _make(meta, "fp16", str(tmp_path))
+    opt = construct_optimizer(model, cfg)
+    scaler = HipGradScaler(init_scale=2.0 ** 40, growth_interval=2)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    loader = _Loader([([clip.cpu()], labels.cpu(), torch.arange(2), {})] * 1)
+    engine.train_epoch(loader, model, opt, scaler, engine.TrainMeter(1, cfg), 0, cfg)
+    assert scaler.get_scale() == 2.0 ** 39 and opt.step_count == 0
+    assert all(torch.equal(before[k], p) for k, p in model.named_parameters())        # skipped step left everything alone
+    scaler.load_state_dict(dict(scaler.state_dict(), scale=4096.0))
+    loader = _Loader([([clip.cpu()], labels.cpu(), torch.arange(2), {})] * 4)
+    engine.train_epoch(loader, model, opt, scaler, engine.TrainMeter(4, cfg), 0, cfg)
+    assert opt.step_count == 4 and scaler.get_scale() == 4096.0 * 4                      # grew twice (interval 2)
+    assert sorted(scaler.state_dict()) == ["_growth_tracker", "backoff_factor", "growth_factor", "growth_interval", "scale"]
+    moved = sum(int(not torch.equal(before[k], p)) for k, p in model.named_parameters())
+    assert moved >= 0.9 * len(before) and all(bool(torch.isfinite(p).all()) for p in model.parameters())
