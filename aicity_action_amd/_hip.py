@@ -87,6 +87,9 @@ def _load(path):
         raise RuntimeError(
             "%s is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C aicity_action_amd/csrc`. There is no CPU fallback for the HIP path." % path)
+    # torch first: it ships its own libamdhip64; if this library were loaded before torch, the process would end up with two HIP
+    # runtimes (the system one resolved for us, the bundled one for torch) and every launch on torch-allocated memory would fail
+    import torch  # noqa: F401
     L = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it
