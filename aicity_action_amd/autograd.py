@@ -104,15 +104,18 @@ class _Ctx(object):
                                              norm.eps, self.act, _st()), "ln")
         return y
 
-    def ln_bwd(self, x, norm, dy, dx, accumulate, rows_per_dy=1, dy_scale=1.0):
+    def ln_bwd(self, x, norm, dy, dx, accumulate, rows_per_dy=1, dy_scale=1.0, base=None):
+        """dx = [base | dx if accumulate | 0] + LN-backward(dy); returns (dgamma, dbeta)."""
         rows, C = x.shape
-        dg = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        dg = self.zeros(C)          # pre-zeroed pool slices + accumulate: the sliced partial reduction needs no memset
+        db = self.zeros(C)
         ws = _ws(self.L.mvit_layernorm_bwd_workspace_bytes(C), x.device)
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
-        _hip.check(self.L.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
-                                             _hip.ptr(dx), 1 if accumulate else 0, _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws),
-                                             rows, C, norm.eps, _st()), "ln_bwd")
+        if base is None and accumulate:
+            base = dx
+        _hip.check(self.L.mvit_layernorm_bwd2(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
+                                              _hip.ptr(base), _hip.ptr(dx), _hip.ptr(dg), _hip.ptr(db), 1, _hip.ptr(ws),
+                                              rows, C, norm.eps, _st()), "ln_bwd")
         return dg, db
 
 
@@ -232,8 +235,8 @@ class _BlockFn(torch.autograd.Function):
         dW1, db1 = hx.wgrad(vn, d_pre, 4 * Cout, Cout)
         d_vn = hx.linear(d_pre, hx.wt(blk.mlp.fc1.weight), None, adt)
         del d_pre
-        d_y = d_out.clone()
-        dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, True)
+        d_y = torch.empty_like(d_out)
+        dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, False, base=d_out)       # d_y = d_out + LN2-backward (no clone)
         del d_vn
         # ---- attention branch: y = r + dp1 * proj(o) ------------------------------------------------------
         g16, gs, grps = hx.scaled16(d_y, dp1, Lq)
@@ -260,11 +263,11 @@ class _BlockFn(torch.autograd.Function):
         for which, dbuf, conv, norm, stride in bpools:
             dconv = torch.empty_like(dbuf)
             dw = hx.zeros(96, 1, 3, 3, 3)
-            dgm = torch.empty(96, dtype=torch.float32, device=dev)
-            dbt = torch.empty(96, dtype=torch.float32, device=dev)
+            dgm = hx.zeros(96)
+            dbt = hx.zeros(96)
             _hip.check(L.mvit_pool_conv_ln_bwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
                                                _hip.ptr(dbuf), _hip.ptr(dconv), _hip.ptr(d_qkv), _hip.ptr(dw), _hip.ptr(dgm),
-                                               _hip.ptr(dbt), 0, _hip.ptr(pws), B, h, T, H, W, stride, norm.eps, act, _st()),
+                                               _hip.ptr(dbt), 1, _hip.ptr(pws), B, h, T, H, W, stride, norm.eps, act, _st()),
                        "pool_bwd")
             pool_grads += [dw, dgm, dbt]
         dWqkv, dbqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
@@ -335,12 +338,15 @@ def forward_train(model, clip):
     assert list(clip.shape[2:]) == model.input_dims and clip.shape[1] == 3, "clip shape %s" % (tuple(clip.shape),)
     pe = model.patch_embed.proj
     x = _StemFn.apply(clip, pe.weight, pe.bias, model.pos_embed_spatial, model.pos_embed_temporal, hx)
-    for g, blk in zip(model.geoms, model.blocks):
+    # drop-path factors of all blocks from ONE uniform draw (common.py:46-59 draws per call: floor(keep + U[B]) / keep)
+    dp_all = None
+    if model.training and any(g.drop_path > 0.0 for g in model.geoms):
+        keep_all = torch.tensor([1.0 - g.drop_path for g in model.geoms], device=dev, dtype=torch.float32).view(-1, 1, 1)
+        dp_all = torch.floor(keep_all + torch.rand(len(model.geoms), 2, B, device=dev, dtype=torch.float32)) / keep_all
+    for i, (g, blk) in enumerate(zip(model.geoms, model.blocks)):
         dp1 = dp2 = None
-        if model.training and g.drop_path > 0.0:
-            keep = 1.0 - g.drop_path                       # common.py:46-59: one draw per sample per call
-            dp1 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
-            dp2 = torch.floor(keep + torch.rand(B, device=dev, dtype=torch.float32)) / keep
+        if dp_all is not None and g.drop_path > 0.0:
+            dp1, dp2 = dp_all[i, 0], dp_all[i, 1]
         if model.use_act_checkpoint and torch.is_grad_enabled():
             # MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037, attention.py checkpoint.checkpoint(blk, x, thw)): keep only
             # the block input, run the block's forward again inside backward.  The drop-path draws are made here, outside.

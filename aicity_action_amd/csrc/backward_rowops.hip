@@ -18,7 +18,7 @@ __device__ __forceinline__ float gsum(float v) {
 template <int C, typename TDY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const TDY* __restrict__ dy, int64_t rows_per_dy, float dy_scale,
-                                                     float* __restrict__ dx, int accumulate, float* __restrict__ part,
+                                                     const float* base, float* dx, float* __restrict__ part,
                                                      int64_t rows, float eps) {
     constexpr int LPR = C / 12;
     constexpr int RPB = 256 / LPR;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 o.y = rstd * (d[i].y - c1 - v[i].y * c2);
                 o.z = rstd * (d[i].z - c1 - v[i].z * c2);
                 o.w = rstd * (d[i].w - c1 - v[i].w * c2);
-                if (accumulate) {
-                    const float4 old = load4(p);
+                if (base) {          // dx = base + LN-backward (base == dx: in-place accumulate; else e.g. the residual-stream gradient)
+                    const float4 old = load4(base + r * C + 4 * (lir + LPR * i));
                     o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
                 }
                 store4(p, o);
@@ -140,30 +140,32 @@ static int launch_reduce_partials(const float* part, int nparts, int width, floa
 extern "C" int64_t mvit_layernorm_bwd_workspace_bytes(int C) { return (int64_t)LN_BWD_MAXBLK * 2 * C * sizeof(float); }
 
 template <int C, typename TDY>
-static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int64_t rpd, float dys, float* dx, int acc,
+static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int64_t rpd, float dys, const float* base, float* dx,
                          float* dgamma, float* dbeta, int acc_param, float* ws, int64_t rows, float eps, hipStream_t st) {
     constexpr int RPB = 256 / (C / 12);
     int64_t blocks = (rows + RPB - 1) / RPB;
     if (blocks > LN_BWD_MAXBLK) blocks = LN_BWD_MAXBLK;
     hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
-                       dx, acc, ws, rows, eps);
+                       base, dx, ws, rows, eps);
     MVIT_LAUNCH_CHECK();
     return launch_reduce_partials(ws, (int)blocks, 2 * C, dgamma, dbeta, C, acc_param, st);
 }
 
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
-extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
-                                  float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                                  int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
+// dx = (dx_base ? dx_base : 0) + LayerNorm-backward(dy); dx_base may alias dx (in-place accumulate) or be a different buffer
+// (the block backward adds the norm-2 branch onto the incoming stream gradient without cloning it first).
+extern "C" int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+                                   float dy_scale, const float* dx_base, float* dx, float* dgamma, float* dbeta,
+                                   int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
     if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || rows_per_dy <= 0) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
 #define LNB(CC)                                                                                                      \
     case CC:                                                                                                         \
         if (dy_dtype == MVIT_F32)                                                                                    \
-            return launch_ln_bwd<CC, float>(x, gamma, dy, rows_per_dy, dy_scale, dx, accumulate_dx, dgamma, dbeta,    \
+            return launch_ln_bwd<CC, float>(x, gamma, dy, rows_per_dy, dy_scale, dx_base, dx, dgamma, dbeta,          \
                                             accumulate_param, workspace, rows, eps, st);                             \
         if (dy_dtype == MVIT_BF16 && rows_per_dy == 1)                                                               \
-            return launch_ln_bwd<CC, bf16_t>(x, gamma, dy, 1, dy_scale, dx, accumulate_dx, dgamma, dbeta,             \
+            return launch_ln_bwd<CC, bf16_t>(x, gamma, dy, 1, dy_scale, dx_base, dx, dgamma, dbeta,                   \
                                              accumulate_param, workspace, rows, eps, st);                            \
         return MVIT_EDTYPE;
     switch (C) {
@@ -171,6 +173,14 @@ extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void
         default: return MVIT_EUNSUPPORTED;
     }
 #undef LNB
+}
+
+// dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
+extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+                                  float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
+                                  int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
+    return mvit_layernorm_bwd2(x, gamma, dy, dy_dtype, rows_per_dy, dy_scale, accumulate_dx ? dx : nullptr, dx, dgamma, dbeta,
+                               accumulate_param, workspace, rows, C, eps, stream);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -119,6 +119,10 @@ int64_t mvit_layernorm_bwd_workspace_bytes(int C);
 int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
                        float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
                        int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream);
+/* Same with an explicit addend: dx = (dx_base ? dx_base : 0) + LN-backward(dy); dx_base may alias dx. */
+int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
+                        const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
+                        int64_t rows, int C, float eps, void* stream);
 
 /* erf-GELU as separate elementwise passes (training keeps the pre-activation; slowfast/models/common.py:28). */
 int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
