@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--streams", type=int, default=2, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -69,7 +70,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     yaml = "MVITV2_FULL_B_16x4_CONV_448.yaml" if args.crop == 448 else "MVITV2_FULL_B_16x4_CONV.yaml"
-    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision])
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision, "HIP.STREAMS", args.streams])
     mv = copy.deepcopy(cfg.MVIT.to_dict())
     train = args.mode == "train"
     if train and world > 1:

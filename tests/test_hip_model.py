@@ -124,3 +124,19 @@ def test_32x3_variant_matches_oracle_on_this_host():
     err = (logits.cpu() - o_logits).abs().max().item()
     print("[32x3 fp32] logits err vs oracle %.2e" % err)
     assert err <= FP32_LOGIT_TOL
+
+
+def test_multi_stream_inference_matches_single_stream():
+    """HIP.STREAMS sub-batches on side streams: same per-clip arithmetic, bit-identical outputs."""
+    z, meta = load_golden("tiny_even")
+    cfg, model = _build(meta, "bf16")
+    clip = synth_clip(8, meta["num_frames"], meta["crop"], 77).cuda()
+    with torch.no_grad():
+        cfg.HIP.STREAMS = 1
+        ref = model([clip]).clone()
+        cfg.HIP.STREAMS = 2
+        out2 = model([clip])
+        cfg.HIP.STREAMS = 4
+        out4 = model([clip])
+    torch.cuda.synchronize()
+    assert torch.equal(ref, out2) and torch.equal(ref, out4)
