@@ -30,7 +30,7 @@ class _Ctx(object):
         self.L = model._lib()
         self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
         self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
-        self._zpool, self._zoff = None, 0
+        self._zpools = {}       # one zero pool per HIP stream (sub-batches of a step run on side streams)
 
     def zeros(self, *shape):
         """fp32 zeros carved from ONE zero-filled buffer per step (the ~290 small gradient buffers of a backward pass
@@ -39,13 +39,15 @@ class _Ctx(object):
         for d in shape:
             n *= int(d)
         n_al = (n + 63) // 64 * 64
-        if self._zpool is None or self._zoff + n_al > self._zpool.numel():
+        dev = next(self.m.parameters()).device
+        key = torch.cuda.current_stream(dev).cuda_stream
+        ent = self._zpools.get(key)
+        if ent is None or ent[1] + n_al > ent[0].numel():
             total = sum((p.numel() + 63) // 64 * 64 for p in self.m.parameters())
-            dev = next(self.m.parameters()).device
-            self._zpool = torch.zeros(max(total, n_al), dtype=torch.float32, device=dev)
-            self._zoff = 0
-        t = self._zpool[self._zoff:self._zoff + n].view(*shape)
-        self._zoff += n_al
+            ent = [torch.zeros(max(total, n_al), dtype=torch.float32, device=dev), 0]
+            self._zpools[key] = ent
+        t = ent[0][ent[1]:ent[1] + n].view(*shape)
+        ent[1] += n_al
         return t
 
     def w(self, p):
@@ -328,39 +330,74 @@ class _HeadFn(torch.autograd.Function):
         return dx.view(B, N, C), dg, dbe, dW, db, None, None
 
 
-def forward_train(model, clip):
-    """Forward in training mode (drop-path + head dropout active when model.training); returns raw logits.
-    Builds the autograd graph when grad mode is on."""
-    hx = _Ctx(model)
-    clip = clip.contiguous().float()
-    B = clip.shape[0]
-    dev = clip.device
-    assert list(clip.shape[2:]) == model.input_dims and clip.shape[1] == 3, "clip shape %s" % (tuple(clip.shape),)
-    pe = model.patch_embed.proj
-    x = _StemFn.apply(clip, pe.weight, pe.bias, model.pos_embed_spatial, model.pos_embed_temporal, hx)
-    # drop-path factors of all blocks from ONE uniform draw (common.py:46-59 draws per call: floor(keep + U[B]) / keep)
+def _draw_train_noise(model, B, C_last, dev):
+    """(drop-path factors [depth,2,B] or None, head-dropout mask [B,C] or None) for a whole batch, one draw each."""
     dp_all = None
     if model.training and any(g.drop_path > 0.0 for g in model.geoms):
+        # common.py:46-59 draws per DropPath call: floor(keep + U[B]) / keep
         keep_all = torch.tensor([1.0 - g.drop_path for g in model.geoms], device=dev, dtype=torch.float32).view(-1, 1, 1)
         dp_all = torch.floor(keep_all + torch.rand(len(model.geoms), 2, B, device=dev, dtype=torch.float32)) / keep_all
+    mask = None
+    if model.training and model.head_dropout > 0.0:
+        p = model.head_dropout                             # head_helper.py:410-411
+        mask = (torch.rand(B, C_last, device=dev) >= p).float() / (1.0 - p)
+    return dp_all, mask
+
+
+def _forward_train_one(model, clip, hx, dp_all, mask):
+    pe = model.patch_embed.proj
+    x = _StemFn.apply(clip, pe.weight, pe.bias, model.pos_embed_spatial, model.pos_embed_temporal, hx)
     for i, (g, blk) in enumerate(zip(model.geoms, model.blocks)):
         dp1 = dp2 = None
         if dp_all is not None and g.drop_path > 0.0:
-            dp1, dp2 = dp_all[i, 0], dp_all[i, 1]
+            dp1, dp2 = dp_all[i, 0].contiguous(), dp_all[i, 1].contiguous()
         if model.use_act_checkpoint and torch.is_grad_enabled():
             # MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037, attention.py checkpoint.checkpoint(blk, x, thw)): keep only
-            # the block input, run the block's forward again inside backward.  The drop-path draws are made here, outside.
+            # the block input, run the block's forward again inside backward.  The drop-path draws are made outside.
             from torch.utils.checkpoint import checkpoint
             x = checkpoint(lambda xx, g=g, blk=blk, dp1=dp1, dp2=dp2: _BlockFn.apply(xx, hx, g, blk, dp1, dp2, *_block_params(blk, g)),
                            x, use_reentrant=False)
         else:
             x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
-    mask = None
-    if model.training and model.head_dropout > 0.0:
-        p = model.head_dropout                             # head_helper.py:410-411
-        mask = (torch.rand(B, x.shape[2], device=dev) >= p).float() / (1.0 - p)
     hp = model.head.projection
     return _HeadFn.apply(x, model.norm.weight, model.norm.bias, hp.weight, hp.bias, mask, hx)
+
+
+def forward_train(model, clip):
+    """Forward in training mode (drop-path + head dropout active when model.training); returns raw logits.
+    Builds the autograd graph when grad mode is on.  With HIP.TRAIN_STREAMS > 1 (default 1: measured slower at B=8 @448, 78.7
+    vs 72.4 ms -- twice the launches and half-size weight-gradient GEMMs outweigh the filled tails) and >= 2 clips per stream the batch
+    runs as sub-batches on side streams (forward and, through autograd's stream bookkeeping, backward): the kernels of one
+    sub-batch fill the last partial wave of workgroups of the other; parameter gradients of the chains are summed by autograd."""
+    hx = _Ctx(model)
+    clip = clip.contiguous().float()
+    B = clip.shape[0]
+    dev = clip.device
+    assert list(clip.shape[2:]) == model.input_dims and clip.shape[1] == 3, "clip shape %s" % (tuple(clip.shape),)
+    dp_all, mask = _draw_train_noise(model, B, model.geoms[-1].dim_out, dev)
+    ns = model.train_streams
+    if ns <= 1 or B < 2 * ns:
+        return _forward_train_one(model, clip, hx, dp_all, mask)
+    for m in model.modules():                      # weight copies are (re)built once, on the caller's stream
+        if isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dim() == 2 and m is not model.head.projection:
+            model._w_pair(m.weight, hx.act)
+    key = (dev.index, ns)
+    if getattr(model, "_side_streams_key", None) != key:
+        model._side_streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        model._side_streams_key = key
+    cur = torch.cuda.current_stream(dev)
+    bounds = [(B * i) // ns for i in range(ns + 1)]
+    outs = []
+    for st_, b0, b1 in zip(model._side_streams, bounds[:-1], bounds[1:]):
+        st_.wait_stream(cur)
+        with torch.cuda.stream(st_):
+            outs.append(_forward_train_one(model, clip[b0:b1], hx, None if dp_all is None else dp_all[:, :, b0:b1],
+                                           None if mask is None else mask[b0:b1]))
+    for st_ in model._side_streams:
+        cur.wait_stream(st_)
+    for o in outs:
+        o.record_stream(cur)
+    return torch.cat(outs, 0)
 
 
 def forward_with_grad(model, clip, return_logits=False):

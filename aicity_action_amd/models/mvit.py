@@ -236,6 +236,12 @@ class MViT(nn.Module):
         hip = getattr(self.cfg, "HIP", None)
         return int(getattr(hip, "STREAMS", 2)) if hip is not None else 2
 
+    @property
+    def train_streams(self):
+        """HIP.TRAIN_STREAMS (default 1): same sub-batching for the training forward/backward (autograd.forward_train)."""
+        hip = getattr(self.cfg, "HIP", None)
+        return int(getattr(hip, "TRAIN_STREAMS", 1)) if hip is not None else 1
+
     def _forward_streams(self, clip, return_logits, ns):
         dev = clip.device
         key = (dev.index, ns)

@@ -206,3 +206,27 @@ def test_fp16_training_with_loss_scaler(tmp_path):
     assert sorted(scaler.state_dict()) == ["_growth_tracker", "backoff_factor", "growth_factor", "growth_interval", "scale"]
     moved = sum(int(not torch.equal(before[k], p)) for k, p in model.named_parameters())
     assert moved >= 0.9 * len(before) and all(bool(torch.isfinite(p).all()) for p in model.parameters())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_multi_stream_train_step_matches_single_stream(tmp_path, precision):
+    """HIP.TRAIN_STREAMS sub-batches (forward and backward on side streams, gradients summed by autograd) vs the single-stream step."""
+    _, meta = load_golden("tiny_even")
+    clip = synth_clip(6, meta["num_frames"], meta["crop"], 21).cuda()
+    labels = torch.tensor([1, 7, 3, 0, 17, 9]).cuda()
+    res = []
+    for ns in (1, 2, 3):
+        cfg, model = _make(meta, precision, str(tmp_path))
+        cfg.HIP.TRAIN_STREAMS = ns
+        model.train()
+        logits = model([clip])
+        loss = engine._loss(cfg, logits, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    for ns, (lg, gr) in zip((2, 3), res[1:]):
+        assert torch.equal(lg, res[0][0]), ns
+        for k in gr:
+            ref = res[0][1][k]
+            tol = (2e-5 if precision == "fp32" else 2e-2) * max(1.0, ref.abs().max().item())
+            assert (gr[k] - ref).abs().max().item() <= tol, (ns, k)
