@@ -163,8 +163,11 @@ def main():
             return e0.elapsed_time(e1) / reps
 
         fwd_ms, bwd_ms, per_f, per_b = 0.0, 0.0, [], []
+        # the launches of the timed region: inference runs HIP.STREAMS sub-batches, so each attention launch covers B / streams clips
+        sub = args.streams if (not train and args.streams > 1 and args.batch >= 2 * args.streams) else 1
+        flops = [f / sub for f in flops]
         for gm, fl in zip(core.geoms, flops):
-            B_, h_ = args.batch, gm.heads
+            B_, h_ = args.batch // sub, gm.heads
             q = torch.randn(B_, h_, gm.lq, 96, device=dev).to(adt)
             k = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
             v = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
@@ -193,14 +196,15 @@ def main():
             if not (args.batch == 8 and args.crop == 448 and args.precision == "bf16" and os.path.exists(path)):
                 return None
             try:
-                return round(float(json.load(open(path))[key]), 0)
+                rec = json.load(open(path))["by_clips_per_launch"].get(str(args.batch // sub))
+                return round(float(rec[key]), 0) if rec else None
             except Exception:
                 return None
 
         def rl(name, tot_flops, tot_ms, per_block, traffic=None):
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops), "avg_launch_ms": round(tot_ms / len(flops), 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": args.batch // sub, "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
         fwd_rl = rl("attn_fwd_%s_kernel" % sfx, sum(flops), fwd_ms, per_f,
