@@ -31,6 +31,7 @@ class _Ctx(object):
         self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
         self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
         self._zpools = {}       # one zero pool per HIP stream (sub-batches of a step run on side streams)
+        self._side_out = []
 
     def zeros(self, *shape):
         """fp32 zeros carved from ONE zero-filled buffer per step (the ~290 small gradient buffers of a backward pass
@@ -72,14 +73,51 @@ class _Ctx(object):
         return y
 
     def wgrad(self, a, dy, N, K, row_scale=None, rps=0):
-        """(dW, db): weight gradient and the fused bias gradient (column sums of the scaled dy)."""
-        dW = self.zeros(N, K)
-        db = self.zeros(N)
+        """(dW, db): weight gradient and the fused bias gradient (column sums of the scaled dy).
+        With HIP.WGRAD_STREAM (default on) the kernel is issued on a side stream: nothing in the backward chain consumes dW, so it
+        runs beside the data-gradient / attention-backward kernels of the same block and fills their partially occupied last
+        waves of workgroups; ``join_side()`` at the end of the block's backward makes the results visible to the caller's stream."""
         adt = _hip.F32 if a.dtype == torch.float32 else _hip.BF16
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
-        _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
-                                            _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
+        side = self._side()
+        if side is None:
+            dW, db = self.zeros(N, K), self.zeros(N)
+            _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
+                                                _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
+            return dW, db
+        cur = torch.cuda.current_stream(a.device)
+        side.wait_stream(cur)                       # the operands were produced on the caller's stream
+        with torch.cuda.stream(side):
+            dW, db = self.zeros(N, K), self.zeros(N)
+            _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
+                                                _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
+        for t in (a, dy, row_scale):
+            if t is not None:
+                t.record_stream(side)               # keep the operands' memory until the side stream is done with it
+        self._side_out += [dW, db]
         return dW, db
+
+    def _side(self):
+        hip = getattr(self.m.cfg, "HIP", None)
+        if not (bool(getattr(hip, "WGRAD_STREAM", True)) if hip is not None else True):
+            return None
+        dev = next(self.m.parameters()).device
+        key = dev.index
+        if getattr(self.m, "_wgrad_stream_key", None) != key:
+            self.m._wgrad_stream = torch.cuda.Stream(device=dev)
+            self.m._wgrad_stream_key = key
+        return self.m._wgrad_stream
+
+    def join_side(self):
+        """The caller's stream waits for the side-stream weight gradients issued so far."""
+        if not self._side_out:
+            return
+        dev = self._side_out[0].device
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(self.m._wgrad_stream)
+        for t in self._side_out:
+            t.record_stream(cur)
+        self._side_out = []
 
     def scaled16(self, dy, row_scale=None, rps=0):
         """fp32 gradient (times its drop-path factor) as the 16-bit GEMM operand; (tensor, row_scale, rps) to pass on."""
@@ -290,6 +328,7 @@ class _BlockFn(torch.autograd.Function):
             d_x = d_r
         dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True)
         grads = [dg1, dbe1, dWqkv, dbqkv, dWp, dbp] + pool_grads + [dg2, dbe2, dW1, db1, dW2, db2] + extra
+        hx.join_side()
         return (d_x.view(B, N, Cin), None, None, None, None, None) + tuple(grads)
 
 

@@ -120,7 +120,7 @@ def _defaults():
         "NUM_GPUS": 1, "NUM_SHARDS": 1, "SHARD_ID": 0, "OUTPUT_DIR": "./tmp", "RNG_SEED": 1, "LOG_PERIOD": 100,
         "DIST_BACKEND": "nccl",
         # build-specific knob (not in the reference): arithmetic of the HIP path, "bf16" or "fp32"
-        "HIP": {"PRECISION": "bf16", "STREAMS": 2, "TRAIN_STREAMS": 1},
+        "HIP": {"PRECISION": "bf16", "STREAMS": 2, "TRAIN_STREAMS": 1, "WGRAD_STREAM": True},
     }
 
 
