@@ -639,6 +639,10 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t>), dim3((unsigned)dblocks), dim3(256), 0, st, (const bf16_t*)dout,
                            (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
         MVIT_LAUNCH_CHECK();
+        // the dQ pass (on st) and the dK/dV pass only share their inputs and delta: fork here, right behind the delta kernel, and
+        // issue the dK/dV pass on the library's side stream so the two passes fill each other's partial last waves of workgroups
+        SideStream* ss = side_stream_for_current_device();
+        hipStream_t skv = (ss && side_fork(ss, st)) ? ss->side : st;
         dim3 gq((Lq + 127) / 128, B * heads);
         static bool dq_attr_done = false;
         if (!dq_attr_done) {
@@ -659,21 +663,22 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             float* dkf = workspace + rows;
             const int64_t nkv = (int64_t)B * heads * Lk * 96;
             float* dvf = dkf + nkv;
-            if (hipMemsetAsync(dkf, 0, 2 * nkv * sizeof(float), st) != hipSuccess) return MVIT_ELAUNCH;
+            if (hipMemsetAsync(dkf, 0, 2 * nkv * sizeof(float), skv) != hipSuccess) return MVIT_ELAUNCH;
             dim3 gk((Lk + 127) / 128, B * heads, nz);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), 0, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                                (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale, sl2);
             MVIT_LAUNCH_CHECK();
             int64_t cb = (nkv / 4 + 255) / 256;
             if (cb > 4096) cb = 4096;
-            hipLaunchKernelGGL(cast2_bf16_kernel, dim3((unsigned)cb), dim3(256), 0, st, dkf, (bf16_t*)dk, dvf, (bf16_t*)dv, nkv / 4);
+            hipLaunchKernelGGL(cast2_bf16_kernel, dim3((unsigned)cb), dim3(256), 0, skv, dkf, (bf16_t*)dk, dvf, (bf16_t*)dv, nkv / 4);
             MVIT_LAUNCH_CHECK();
-            return MVIT_OK;
+        } else {
+            dim3 gk((Lk + 127) / 128, B * heads);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), 0, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale, sl2);
+            MVIT_LAUNCH_CHECK();
         }
-        dim3 gk((Lk + 127) / 128, B * heads);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                           (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale, sl2);
-        MVIT_LAUNCH_CHECK();
+        if (skv != st && !side_join(ss, st)) return MVIT_ELAUNCH;
         return MVIT_OK;
     }
     if (act_dtype != MVIT_F32) return MVIT_EDTYPE;

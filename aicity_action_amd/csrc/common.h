@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 MViT kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/mvit_hip.h"
@@ -135,6 +136,37 @@ __device__ __forceinline__ void xcd_group_map(int& tile, int& group) {
         group = gq * 8 + xcd;
         tile = slot - gq * nt;
     }
+}
+
+// A library-owned side stream per device with a fork / join pair of events: independent kernels of one entry point (the dQ and
+// the dK/dV pass of the attention backward) are issued on `st` and on the side stream between fork() and join(), so each fills
+// the other's partially occupied last wave of workgroups.  After join() everything is ordered on `st` again, so callers see
+// ordinary single-stream semantics (buffers may be reused / freed in stream order).  Returns nullptr when disabled
+// (MVIT_NO_SIDE_STREAM) or on failure: the caller then launches everything on `st`.
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+static inline SideStream* side_stream_for_current_device() {
+    static SideStream tab[16];
+    static const bool off = getenv("MVIT_NO_SIDE_STREAM") != nullptr;
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream* s = &tab[dev];
+    if (!s->side) {
+        if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) { s->side = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return s;
+}
+static inline bool side_fork(SideStream* s, hipStream_t st) {
+    return s && hipEventRecord(s->ev_fork, st) == hipSuccess && hipStreamWaitEvent(s->side, s->ev_fork, 0) == hipSuccess;
+}
+static inline bool side_join(SideStream* s, hipStream_t st) {
+    return s && hipEventRecord(s->ev_join, s->side) == hipSuccess && hipStreamWaitEvent(st, s->ev_join, 0) == hipSuccess;
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

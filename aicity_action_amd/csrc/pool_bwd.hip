@@ -366,11 +366,17 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     if (prow < PB_MAXBLK) prow = PB_MAXBLK;
     float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes2
     const bool tiled = stride_hw == 1 || stride_hw == 2;
+    // d_conv is complete after the first kernel; the conv weight gradient (+ its partial-row reduction) only reads it, so it is
+    // issued on the library's side stream and runs beside the d_gamma / d_beta reductions and the data gradient
 #define RUN(TA)                                                                                                            \
+    SideStream* ss = nullptr;                                                                                              \
+    hipStream_t sw = st;                                                                                                   \
     if (tiled) {                                                                                                           \
         const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
                                                           H, W, stride_hw, eps, act_dtype, st);                            \
         if (nrows < 0) return nrows;                                                                                       \
+        ss = side_stream_for_current_device();                                                                             \
+        if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, nrows, 96, dgamma, dgamma, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
         /* d_beta = column sums of dout (workspace rows are free again after the reduce above, same stream) */             \
         const int rcb = mvit_colsum(dout, act_dtype, tot_out, 96, nullptr, 0, dbeta, accumulate_param, workspace, stream);  \
@@ -379,22 +385,25 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
         hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w, \
                            gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);      \
         MVIT_LAUNCH_CHECK();                                                                                               \
+        ss = side_stream_for_current_device();                                                                             \
+        if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
+    }                                                                                                                      \
+    if (tiled) {                                                                                                           \
+        const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
+                                                      act_dtype, sw);                                                      \
+        if (wr < 0) return wr;                                                                                             \
+        { const int rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, sw); if (rr_ != MVIT_OK) return rr_; }       \
+    } else {                                                                                                               \
+        hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, sw, (const TA*)qkv, ld, chan_off,     \
+                           (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                 \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+        { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, sw); if (rr_ != MVIT_OK) return rr_; }  \
     }                                                                                                                      \
     hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
                        chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
     MVIT_LAUNCH_CHECK();                                                                                                   \
-    if (tiled) {                                                                                                           \
-        const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
-                                                      act_dtype, st);                                                      \
-        if (wr < 0) return wr;                                                                                             \
-        { const int rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, st); if (rr_ != MVIT_OK) return rr_; }       \
-    } else {                                                                                                               \
-        hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, st, (const TA*)qkv, ld, chan_off,     \
-                           (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                 \
-        MVIT_LAUNCH_CHECK();                                                                                               \
-        { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, st); if (rr_ != MVIT_OK) return rr_; }  \
-    }
+    if (sw != st && !side_join(ss, st)) return MVIT_ELAUNCH;
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN
     return MVIT_OK;
