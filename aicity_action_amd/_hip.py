@@ -38,6 +38,9 @@ _SIGS = {
     "mvit_cast_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_p]),
     "mvit_cast_rows_f32_to_bf16": (c_i, [c_p, c_p, c_l, c_i, c_p, c_l, c_p]),
     "mvit_cast_transpose_f32_to_bf16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    "mvit_side_stream": (c_p, []),
+    "mvit_side_fork": (c_i, [c_p]),
+    "mvit_side_join": (c_i, [c_p]),
     "mvit_head_split_fwd": (c_i, [c_p, c_l, c_i, c_p, c_i, c_i, c_l, c_i, c_p]),
     "mvit_head_split_bwd": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_i, c_p]),
     "mvit_window_preprocess": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),

@@ -221,10 +221,14 @@ class _BlockFn(torch.autograd.Function):
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:
             _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, _st()), "head_split")
+        forked = L.mvit_side_fork(_st()) == 0          # k / v pooling convs beside the q one (independent readers of qkv)
+        side = L.mvit_side_stream() if forked else _st()
         for which, buf, conv, norm, stride in pools:
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
-                                               _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W, stride, norm.eps, act, _st()),
-                       "pool")
+                                               _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W, stride, norm.eps, act,
+                                               _st() if which == 0 else side), "pool")
+        if forked:
+            _hip.check(L.mvit_side_join(_st()), "side_join")
         o = torch.empty(Mq, Cout, dtype=adt, device=dev)
         lse = torch.empty(B, h, Lq, dtype=torch.float32, device=dev)
         addq = 1 if hx.m.use_query_residual_pool else 0

@@ -394,6 +394,24 @@ extern "C" int mvit_head_split_bwd(const void* dout, void* dqkv, int64_t ld, int
     return launch_head_split<true>(dqkv, ld, chan_off, const_cast<void*>(dout), B, heads, N, act_dtype, stream);
 }
 
+// Fork / join on the library's side stream for callers that issue independent operators themselves (the k / v pooling convs
+// beside the q one): after mvit_side_fork(stream) the handle returned by mvit_side_stream() may be passed as the `stream`
+// argument of any entry point; mvit_side_join(stream) orders everything issued there before later work on `stream`.
+extern "C" void* mvit_side_stream(void) {
+    SideStream* ss = side_stream_for_current_device();
+    return ss ? reinterpret_cast<void*>(ss->side) : nullptr;
+}
+extern "C" int mvit_side_fork(void* stream) {
+    SideStream* ss = side_stream_for_current_device();
+    if (!ss) return MVIT_EUNSUPPORTED;
+    return side_fork(ss, as_stream(stream)) ? MVIT_OK : MVIT_ELAUNCH;
+}
+extern "C" int mvit_side_join(void* stream) {
+    SideStream* ss = side_stream_for_current_device();
+    if (!ss) return MVIT_EUNSUPPORTED;
+    return side_join(ss, as_stream(stream)) ? MVIT_OK : MVIT_ELAUNCH;
+}
+
 #ifdef MVIT_HALF_IS_FP16
 extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r1 (16-bit type: fp16)"; }
 #else

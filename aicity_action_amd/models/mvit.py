@@ -254,10 +254,14 @@ class MViT(nn.Module):
                 self._w(m.weight, act)
         cur = torch.cuda.current_stream(dev)
         outs = []
-        for st_, part in zip(self._side_streams, torch.chunk(clip, ns, dim=0)):
-            st_.wait_stream(cur)
-            with torch.cuda.stream(st_):
-                outs.append(self._forward_hip(part.contiguous(), return_logits))
+        self._substreams_active = True
+        try:
+            for st_, part in zip(self._side_streams, torch.chunk(clip, ns, dim=0)):
+                st_.wait_stream(cur)
+                with torch.cuda.stream(st_):
+                    outs.append(self._forward_hip(part.contiguous(), return_logits))
+        finally:
+            self._substreams_active = False
         for st_ in self._side_streams:
             cur.wait_stream(st_)
         def cat(ts):
@@ -347,10 +351,15 @@ class MViT(nn.Module):
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:       # pool_q is None (Q_POOL_ALL off): the query is the head-split slice itself, no LayerNorm (attention.py:14-15)
             _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, st), "head_split")
+        # the three pooling convs are independent readers of qkv: k and v go to the library's side stream, q stays here
+        forked = (not getattr(self, "_substreams_active", False)) and L.mvit_side_fork(st) == 0    # (one side stream: not under sub-batch streams)
+        side = L.mvit_side_stream() if forked else st
         for which, buf, conv, norm, stride in pools:
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight),
                                                _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W,
-                                               stride, norm.eps, act, st), "pool%d" % which)
+                                               stride, norm.eps, act, st if which == 0 else side), "pool%d" % which)
+        if forked:
+            _hip.check(L.mvit_side_join(st), "side_join")
         del qkv
         # 4. fused attention (+ pooled-q residual), heads merged on store   attention.py:267-279
         o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)

@@ -216,6 +216,14 @@ int mvit_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mvit_cast_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols, const float* row_scale,
                                int64_t rows_per_scale, void* stream);
 
+/* Side stream of the library (one per device, created on first use) with a fork / join pair: independent operators may be issued
+ * concurrently -- mvit_side_fork(stream); op(..., mvit_side_stream()); op(..., stream); mvit_side_join(stream) -- so that each
+ * fills the other's partially occupied last wave of workgroups.  After the join everything is ordered on `stream` again.
+ * mvit_side_fork / _join return MVIT_EUNSUPPORTED when the side stream is disabled (env MVIT_NO_SIDE_STREAM): issue on `stream`. */
+void* mvit_side_stream(void);
+int mvit_side_fork(void* stream);
+int mvit_side_join(void* stream);
+
 /* Query path of blocks WITHOUT a pooling conv (MVIT.Q_POOL_ALL off -> pool_q is None, attention.py:14-15,131-134,239-246):
  * out[b][g][n][:] = qkv[b][n][chan_off + g*96 : +96] (head split only, no LayerNorm); _bwd copies dout back into the slice of the
  * fused gradient buffer. */
