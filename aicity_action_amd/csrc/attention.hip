@@ -36,8 +36,8 @@ __device__ __forceinline__ bf16x4 lds_tr16(uint32_t addr) {
     return v;
 }
 
-template <bool ADD_Q>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+template <bool ADD_Q, int NW>      // NW waves x 32 queries per workgroup
+__global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                             const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                             float* __restrict__ LSE, int heads, int Lq, int Lk,
                                                             float scale_log2e) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qtile * A_QB + wave * A_QW;
+    const int q0 = qtile * (A_QW * NW) + wave * A_QW;
 
     const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
     const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
@@ -63,40 +63,41 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     for (int ks = 0; ks < 6; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
 
     // K/V tiles go global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 B land linearly at a wave-uniform LDS
-    // base), three K and three V pieces of 1 KiB per wave and tile.  A tile is one contiguous 12 KiB block of K (and V);
-    // LDS position p = 64*piece + lane of the K image holds chunk (p%12 - rot(row)) of row p/12, so the rotation swizzle
-    // is applied to the SOURCE address; the V image is linear.  Nothing is staged in registers.
-    uint32_t gk_off[3], gv_off[3];
-    int p_row[3], p_kc[3], p_vc[3];
+    // base): the 24 pieces of 1 KiB of a tile (12 of the K image, then 12 of the V image) are dealt PW = 24/NW per wave, so a
+    // wave moves only K or only V.  A tile is one contiguous 12 KiB block of K (and V); LDS position p = 64*piece + lane of the
+    // K image holds chunk (p%12 - rot(row)) of row p/12, so the rotation swizzle is applied to the SOURCE address; the V image
+    // is linear.  Nothing is staged in registers.
+    constexpr int PW = 24 / NW;
+    const bool is_v = wave >= NW / 2;                       // wave-uniform
+    const char* src_bh = reinterpret_cast<const char*>(is_v ? Vb : Kb);
+    uint32_t g_off[PW];
+    int p_row[PW], p_c[PW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int p = 64 * (3 * wave + i) + lane;
+    for (int i = 0; i < PW; ++i) {
+        const int piece = PW * wave + i - (is_v ? 12 : 0);
+        const int p = 64 * piece + lane;
         const int row = p / 12, pos = p - row * 12;
-        int c = pos - ((row >> 2) & 3);
-        c = c < 0 ? c + 12 : c;
-        p_row[i] = row; p_kc[i] = c; p_vc[i] = pos;
-        gk_off[i] = (uint32_t)(row * 12 + c) * 16u;
-        gv_off[i] = (uint32_t)p * 16u;
+        int c = pos;
+        if (!is_v) {
+            c = pos - ((row >> 2) & 3);
+            c = c < 0 ? c + 12 : c;
+        }
+        p_row[i] = row; p_c[i] = c;
+        g_off[i] = (uint32_t)(row * 12 + c) * 16u;
     }
     auto dma = [&](int k0, int stage) {
-        const char* kt_base = reinterpret_cast<const char*>(Kb) + (int64_t)k0 * A_ROWB;   // wave-uniform
-        const char* vt_base = reinterpret_cast<const char*>(Vb) + (int64_t)k0 * A_ROWB;
-        char* dst = smem + stage * A_TILEB + 1024 * (3 * wave);
+        const char* t_base = src_bh + (int64_t)k0 * A_ROWB;   // wave-uniform
+        char* dst = smem + stage * A_TILEB + 1024 * (PW * wave);
         if (k0 + A_KT <= Lk) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                __builtin_amdgcn_global_load_lds((a_gptr_t*)(kt_base + gk_off[i]), (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((a_gptr_t*)(vt_base + gv_off[i]), (a_lptr_t*)(dst + A_KT * A_ROWB + 1024 * i), 16, 0, 0);
-            }
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(t_base + g_off[i]), (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
         } else {        // tail tile: rows past Lk re-read the last valid row (finite data; their scores are masked to -inf)
             const int last = Lk - 1 - k0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < PW; ++i) {
                 const int row = p_row[i] < last ? p_row[i] : last;
-                __builtin_amdgcn_global_load_lds((a_gptr_t*)(kt_base + (uint32_t)(row * 12 + p_kc[i]) * 16u),
-                                                 (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((a_gptr_t*)(vt_base + (uint32_t)(row * 12 + p_vc[i]) * 16u),
-                                                 (a_lptr_t*)(dst + A_KT * A_ROWB + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((a_gptr_t*)(t_base + (uint32_t)(row * 12 + p_c[i]) * 16u), (a_lptr_t*)(dst + 1024 * i), 16, 0, 0);
             }
         }
     };
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #define STAMP(i)
 #endif
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed once at most the 6 pieces of tile kt+1 are still outstanding (VMEM returns in order)
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // tile kt has landed once at most the PW pieces of tile kt+1 are still outstanding (VMEM returns in order)
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(0)
         __builtin_amdgcn_s_barrier();       // everyone's pieces landed; everyone is done with the stage refilled below
@@ -371,21 +372,24 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
     hipStream_t st = as_stream(stream);
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (act_dtype == MVIT_BF16) {
-        dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
+        static const int nw_env = getenv("MVIT_ATT_WAVES") ? atoi(getenv("MVIT_ATT_WAVES")) : 4;
+        const int NWr = nw_env == 8 ? 8 : 4;
+        dim3 grid((Lq + 32 * NWr - 1) / (32 * NWr), B * heads);
         const float sl2 = scale * 1.44269504088896340736f;
         static bool attr_done = false;
         if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess)
                 return MVIT_ELAUNCH;
             attr_done = true;
         }
-        if (add_q)
-            hipLaunchKernelGGL((attn_fwd_bf16_kernel<true>), grid, dim3(256), A_STAGES * A_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
-        else
-            hipLaunchKernelGGL((attn_fwd_bf16_kernel<false>), grid, dim3(256), A_STAGES * A_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
+#define ATT_LAUNCH(AQ, NWW) hipLaunchKernelGGL((attn_fwd_bf16_kernel<AQ, NWW>), grid, dim3(64 * NWW), A_STAGES * A_TILEB, st, (const bf16_t*)q, \
+                                               (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2)
+        if (add_q) { if (NWr == 8) ATT_LAUNCH(true, 8); else ATT_LAUNCH(true, 4); }
+        else { if (NWr == 8) ATT_LAUNCH(false, 8); else ATT_LAUNCH(false, 4); }
+#undef ATT_LAUNCH
     } else if (act_dtype == MVIT_F32) {
         dim3 grid((Lq + 127) / 128, B * heads);
         hipLaunchKernelGGL(attn_fwd_f32_kernel, grid, dim3(128), 0, st, (const float*)q, (const float*)k, (const float*)v,
