@@ -163,7 +163,7 @@ struct PoolTile {
     static constexpr int PF = (NCHUNK + NT - 1) / NT;   // prefetch registers (uint4) per thread
     static constexpr int IN_BYTES = IH * IW * 96 * (int)sizeof(TA);
     static constexpr int W_BYTES = 27 * 96 * 4;          // weights [tap][channel] fp32
-    static constexpr bool DB = (S == 1);                // double-buffered input tile + register prefetch
+    static constexpr bool DB = false;                   // single input tile + register prefetch: 54 KB -> 3 workgroups per CU
     static constexpr int NBUF = DB ? 2 : 1;
     static constexpr int SMEM = NBUF * IN_BYTES + NTOK * 96 * 4 + W_BYTES;
 };
