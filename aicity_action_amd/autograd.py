@@ -9,6 +9,8 @@ head_helper.py:410-411) and the autograd graph.
 Mixed-precision policy of the bf16 path: MFMA operands and stored activations bf16; residual stream, LayerNorm
 statistics, softmax statistics, accumulators, parameter gradients and optimizer state fp32 (fp32 masters).
 """
+import os
+
 import torch
 
 from . import _hip
@@ -99,7 +101,7 @@ class _Ctx(object):
 
     def _side(self):
         hip = getattr(self.m.cfg, "HIP", None)
-        if not (bool(getattr(hip, "WGRAD_STREAM", True)) if hip is not None else True):
+        if os.environ.get("MVIT_WGRAD_STREAM", "1") == "0" or not (bool(getattr(hip, "WGRAD_STREAM", True)) if hip is not None else True):
             return None
         dev = next(self.m.parameters()).device
         key = dev.index
