@@ -215,7 +215,13 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const TA* __restrict__ 
         const int64_t it = it0 + (threadIdx.x >> 2);
         if (it >= total) continue;
         int64_t rem = it;
-        const int x = (int)(rem % W); rem /= W;
+        int x = (int)(rem % W); rem /= W;
+        // strided pooling: walk x class by class (x mod s) so that the 16 tokens of a wave share their valid tap set -- the tap
+        // loop's parity tests become wave-uniform branches instead of 27 masked iterations
+        if (s > 1 && W % s == 0) {
+            const int nxs = W / s;
+            x = (x % nxs) * s + x / nxs;
+        }
         const int y = (int)(rem % H); rem /= H;
         const int t = (int)(rem % T); rem /= T;
         const int gh = (int)(rem % heads);
