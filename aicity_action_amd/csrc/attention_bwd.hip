@@ -7,6 +7,8 @@
 // Both passes are the forward kernel's skeleton (resident operand as MFMA B fragments in registers, streamed tiles in
 // LDS, accumulator tile reused directly as the B operand of the second product); recomputing S/dP in both passes
 // costs 7 instead of 5 matrix products but keeps the pass deterministic and free of the 1.3 TB/s atomic ceiling.
+#include <type_traits>
+
 #include "common.h"
 
 #define B_T 64            // streamed rows per tile
@@ -234,23 +236,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const int kbase = kt * B_T;
         const bool tail = kbase + B_T > Lk;
         bf16x8 dsf[4];
+        // dS = P (dP - delta); the key mask of the tail tile lives in its own (wave-uniform) branch -- inside the unrolled loops
+        // the compiler if-converted it into a compare + two selects per element of EVERY tile (130 of 280 VALU instructions)
+        auto make_ds = [&](auto tail_tag) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                float dsv[8];
+                for (int sh = 0; sh < 2; ++sh) {
+                    float dsv[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int i = 8 * sh + jj;
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2e, -lse));
-                    if (tail) {
-                        const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        p = key < Lk ? p : 0.f;
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int i = 8 * sh + jj;
+                        float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2e, -lse));
+                        if (decltype(tail_tag)::value) {
+                            const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            p = key < Lk ? p : 0.f;
+                        }
+                        dsv[jj] = p * (dp[kb][i] - dlt);
                     }
-                    dsv[jj] = p * (dp[kb][i] - dlt);
+                    dsf[2 * kb + sh] = pack8(dsv);
                 }
-                dsf[2 * kb + sh] = pack8(dsv);
-            }
+        };
+        if (tail) make_ds(std::true_type{});
+        else make_ds(std::false_type{});
         // dQ^T += K^T . dS^T
         bf16x4 tb[12];
         B_WAIT6(ta, 0);
