@@ -42,30 +42,46 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const T* __restrict__ dO, const T* __restrict__ O,
                                                              const T* __restrict__ Q, float* __restrict__ delta, int B,
                                                              int heads, int Lq, int add_q) {
+    // 4 lanes per (b, g, q) row; lane j owns the 16-byte chunks j, j+4, ... of the row's 96 channels
+    constexpr int CW = 16 / sizeof(T);          // channels per 16-byte chunk
+    constexpr int NCH = 96 / CW / 4;            // chunks per lane
     const int64_t total = (int64_t)B * heads * Lq;
-    const int j = threadIdx.x & 7;
-    for (int64_t it0 = (int64_t)blockIdx.x * 32; it0 < total; it0 += (int64_t)gridDim.x * 32) {
-        const int64_t it = it0 + (threadIdx.x >> 3);
+    const int j = threadIdx.x & 3;
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < total; it0 += (int64_t)gridDim.x * 64) {
+        const int64_t it = it0 + (threadIdx.x >> 2);
         const bool ok = it < total;
         const int64_t itc = ok ? it : total - 1;
         const int q = (int)(itc % Lq);
         const int g = (int)((itc / Lq) % heads);
         const int b = (int)(itc / ((int64_t)Lq * heads));
-        const int64_t orow = ((int64_t)b * Lq + q) * heads * 96 + g * 96 + 12 * j;
+        const int64_t orow = ((int64_t)b * Lq + q) * heads * 96 + g * 96;
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 12; e += 4) {
-            const float4 d = load4(dO + orow + e);
-            float4 o = load4(O + orow + e);
-            if (add_q) {
-                const float4 qq = load4(Q + itc * 96 + 12 * j + e);
-                o.x -= qq.x; o.y -= qq.y; o.z -= qq.z; o.w -= qq.w;
+        for (int i = 0; i < NCH; ++i) {
+            const int c0 = CW * (j + 4 * i);
+            float4 d0, d1, o0, o1;
+            if constexpr (CW == 8) {
+                load8(dO + orow + c0, d0, d1);
+                load8(O + orow + c0, o0, o1);
+                if (add_q) {
+                    float4 q0, q1;
+                    load8(Q + itc * 96 + c0, q0, q1);
+                    o0.x -= q0.x; o0.y -= q0.y; o0.z -= q0.z; o0.w -= q0.w;
+                    o1.x -= q1.x; o1.y -= q1.y; o1.z -= q1.z; o1.w -= q1.w;
+                }
+                s += (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y) + (d1.z * o1.z + d1.w * o1.w);
+            } else {
+                d0 = load4(dO + orow + c0);
+                o0 = load4(O + orow + c0);
+                if (add_q) {
+                    const float4 q0 = load4(Q + itc * 96 + c0);
+                    o0.x -= q0.x; o0.y -= q0.y; o0.z -= q0.z; o0.w -= q0.w;
+                }
+                s += (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w);
             }
-            s += d.x * o.x + d.y * o.y + d.z * o.z + d.w * o.w;
         }
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
         if (ok && j == 0) delta[it] = s;
     }
 }
@@ -640,7 +656,7 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
     const int64_t rows = (int64_t)B * heads * Lq;
-    int64_t dblocks = (rows + 31) / 32;
+    int64_t dblocks = (rows + 63) / 64;
     if (dblocks > 16384) dblocks = 16384;
     const float sl2 = scale * 1.44269504088896340736f;
     if (act_dtype == MVIT_BF16) {
