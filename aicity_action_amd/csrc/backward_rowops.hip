@@ -395,7 +395,7 @@ extern "C" int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float
 // ----------------------------------------------------------------------------------------------
 // Column sums: out[n] (+)= scale-weighted sum over rows of a[M][N]  (bias gradients; two-stage).
 // ----------------------------------------------------------------------------------------------
-#define CS_MAXBLK 256
+#define CS_MAXBLK 512      // 2 workgroups per CU (HBM-bound); 512 x 96 floats is also what the pooling backward's workspace holds
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t M, int N,
                                                              const float* __restrict__ row_scale, int64_t rps,
@@ -449,9 +449,7 @@ extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const f
     else
         return MVIT_EDTYPE;
     MVIT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, st, workspace, blocks, N, out, out, N, accumulate);
-    MVIT_LAUNCH_CHECK();
-    return MVIT_OK;
+    return launch_reduce_partials(workspace, blocks, N, out, out, N, accumulate, st);
 }
 
 // ----------------------------------------------------------------------------------------------
