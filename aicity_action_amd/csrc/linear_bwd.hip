@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
                                                            float* __restrict__ dW, float* __restrict__ db, int64_t M, int N,
                                                            int K, int mchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntq = K / WB_BQ;
+    const int ntq = (K + WB_BQ - 1) / WB_BQ;      // ragged last tiles (N, K multiples of 32): sources clamped, results masked
     const int n0 = (blockIdx.x / ntq) * WB_BP, k0 = (blockIdx.x % ntq) * WB_BQ;
     const int64_t mbeg = (int64_t)blockIdx.y * mchunk;
     const int64_t mend = mbeg + mchunk < M ? mbeg + mchunk : M;     // multiple of 64 (checked by the launcher)
@@ -201,14 +201,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) {       // dy image: piece = 4 rows x 256 B
         const int row = 4 * (4 * wave + i) + (lane >> 4), c = lane & 15;
         const int seg = (c >> 2) ^ (row & 3);
-        p_src[i] = (int64_t)row * ldd + n0 + 8 * (4 * seg + (c & 3));
+        int col = n0 + 8 * (4 * seg + (c & 3));
+        col = col + 8 <= N ? col : N - 8;                  // columns past N: re-read valid memory (those accumulators are dropped)
+        p_src[i] = (int64_t)row * ldd + col;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {       // a image: 24 chunks per row, pieces run across rows
         const int x = 64 * (6 * wave + i) + lane;
         const int row = x / 24, c = x - row * 24;
         const int seg = (c >> 2) ^ ((row >> 1) & 1);
-        q_src[i] = (int64_t)row * lda + k0 + 8 * (4 * seg + (c & 3));
+        int col = k0 + 8 * (4 * seg + (c & 3));
+        col = col + 8 <= K ? col : K - 8;
+        q_src[i] = (int64_t)row * lda + col;
     }
     auto dma = [&](int64_t m0, int buf) {
         char* base = smem + buf * WB_BUF;
@@ -293,13 +297,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                atomicAdd(dW + (int64_t)n * K + k0 + 96 * wq + 32 * qb + r, acc[pb][qb][i]);
+                const int kk = k0 + 96 * wq + 32 * qb + r;
+                if (n < N && kk < K) atomicAdd(dW + (int64_t)n * K + kk, acc[pb][qb][i]);
             }
     if (do_bias && r == 0) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) atomicAdd(db + n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h, bacc[pb][i]);
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (n < N) atomicAdd(db + n, bacc[pb][i]);
+            }
     }
 }
 
@@ -388,7 +396,7 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return MVIT_EUNSUPPORTED;
     static const bool use_big = getenv("MVIT_WGRAD_NO_BIG") == nullptr;
-    if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !row_scale && N % WB_BP == 0 && K % WB_BQ == 0 && M % 64 == 0 &&
+    if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !row_scale && N % 32 == 0 && K % 32 == 0 && N >= 32 && K >= 32 && M % 64 == 0 &&
         64 * lda < (1ll << 31) && 64 * ldd < (1ll << 31)) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -396,7 +404,7 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
                 return MVIT_ELAUNCH;
             attr_done = true;
         }
-        const int64_t bt = (int64_t)(N / WB_BP) * (K / WB_BQ);
+        const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
         int64_t nch = (512 + bt - 1) / bt;                      // ~2 workgroups per CU in total
         int64_t bmc = ((M / 64 + nch - 1) / nch) * 64;          // rows per chunk, multiple of 64
         if (bmc < 512) bmc = 512;

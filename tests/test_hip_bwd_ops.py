@@ -105,7 +105,8 @@ def test_cast_rows_with_drop_path_scale(hip_lib, rows, cols, rps):
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("M,N,K,scaled", [(1000, 288, 96, False), (2500, 96, 384, True), (129, 384, 192, False),
                                            (3000, 192, 768, True), (700, 576, 192, False), (300, 768, 96, False),
-                                           (300, 1152, 96, False), (4096, 384, 384, False), (6336, 384, 192, False),
+                                           (300, 1152, 96, False), (4096, 384, 384, False), (6336, 384, 192, False), (1024, 288, 96, False), (1280, 96, 384, False),
+                                           (640, 576, 192, False), (2048, 96, 96, False), (1920, 192, 768, False),
                                            (64, 384, 192, False)])
 def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
     a = _act(_rnd(M, K, seed=11), act)
