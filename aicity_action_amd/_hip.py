@@ -41,6 +41,8 @@ _SIGS = {
     "mvit_side_stream": (c_p, []),
     "mvit_side_fork": (c_i, [c_p]),
     "mvit_side_join": (c_i, [c_p]),
+    "mvit_cast_desc_bytes": (c_i, []),
+    "mvit_cast_transpose_multi": (c_i, [c_p, c_i, c_i, c_p]),
     "mvit_head_split_fwd": (c_i, [c_p, c_l, c_i, c_p, c_i, c_i, c_l, c_i, c_p]),
     "mvit_head_split_bwd": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_i, c_p]),
     "mvit_window_preprocess": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),

@@ -394,6 +394,53 @@ extern "C" int mvit_head_split_bwd(const void* dout, void* dqkv, int64_t ld, int
     return launch_head_split<true>(dqkv, ld, chan_off, const_cast<void*>(dout), B, heads, N, act_dtype, stream);
 }
 
+// All GEMM weights of the model in ONE launch: desc[t] = {src, dst, dst_t, rows, cols, first_tile}; workgroup b finds its tensor by
+// binary search over first_tile and handles one 64x64 tile of it (same tile body as cast_transpose_kernel).
+struct CastDesc {
+    const float* src;
+    bf16_t* dst;
+    bf16_t* dst_t;
+    int rows, cols;
+    int first_tile, pad;
+};
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastDesc* __restrict__ desc, int ntensors) {
+    __shared__ bf16_t tile[64][66];
+    int lo = 0, hi = ntensors - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].first_tile <= b) lo = mid; else hi = mid - 1;
+    }
+    const CastDesc d = desc[lo];
+    const int tl = b - d.first_tile, tcx = (d.cols + 63) / 64;
+    const int r0 = (tl / tcx) * 64, c0 = (tl % tcx) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16_t v = 0;
+        if (r < d.rows && c < d.cols) {
+            v = f32_to_bf16(d.src[(int64_t)r * d.cols + c]);
+            d.dst[(int64_t)r * d.cols + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < d.rows && c < d.cols) d.dst_t[(int64_t)c * d.rows + r] = tile[tx][i];
+    }
+}
+
+extern "C" int mvit_cast_desc_bytes(void) { return (int)sizeof(CastDesc); }
+
+extern "C" int mvit_cast_transpose_multi(const void* desc_table, int ntensors, int total_tiles, void* stream) {
+    if (!desc_table || ntensors <= 0 || total_tiles <= 0) return MVIT_EINVAL;
+    hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, as_stream(stream),
+                       (const CastDesc*)desc_table, ntensors);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 // Fork / join on the library's side stream for callers that issue independent operators themselves (the k / v pooling convs
 // beside the q one): after mvit_side_fork(stream) the handle returned by mvit_side_stream() may be passed as the `stream`
 // argument of any entry point; mvit_side_join(stream) orders everything issued there before later work on `stream`.

@@ -196,22 +196,76 @@ class MViT(nn.Module):
         return ent[1]
 
     def _w_pair(self, param, act):
-        """(W, W^T) of a 2-D GEMM weight in the activation dtype, produced together by one kernel and cached per parameter
-        version (training: the forward reads W, the data-gradient GEMM W^T)."""
-        key = ("pair", self.precision, id(param))
-        ent = self._bf16_cache.get(key)
-        if ent is None or ent[0] != param._version or ent[1].device != param.device:
-            if act == _hip.F32:
+        """(W, W^T) of a 2-D GEMM weight in the activation dtype (training: the forward reads W, the data-gradient GEMM W^T).
+        The copies of ALL GEMM weights live in persistent buffers and are refreshed together by one multi-tensor kernel whenever
+        any parameter's version counter moved (optimizer step, load_state_dict)."""
+        if act == _hip.F32:
+            key = ("pair32", id(param))
+            ent = self._bf16_cache.get(key)
+            if ent is None or ent[0] != param._version or ent[2].device != param.device:
                 ent = (param._version, param, param.detach().t().contiguous())
-            else:
+                self._bf16_cache[key] = ent
+            return ent[1], ent[2]
+        st = self._pairs_state()
+        ent = st["by_id"].get(id(param))
+        if ent is None:                             # not one of the block GEMM weights: single-tensor path
+            key = ("pair", self.precision, id(param))
+            e2 = self._bf16_cache.get(key)
+            if e2 is None or e2[0] != param._version or e2[1].device != param.device:
                 R, C = param.shape
                 w = torch.empty(R, C, dtype=self._half_dtype(), device=param.device)
                 wt = torch.empty(C, R, dtype=self._half_dtype(), device=param.device)
-                st = torch.cuda.current_stream().cuda_stream
-                _hip.check(self._lib().mvit_cast_transpose_f32_to_bf16(_hip.ptr(param), _hip.ptr(w), _hip.ptr(wt), R, C, st), "cast_t")
-                ent = (param._version, w, wt)
-            self._bf16_cache[key] = ent
+                _hip.check(self._lib().mvit_cast_transpose_f32_to_bf16(_hip.ptr(param), _hip.ptr(w), _hip.ptr(wt), R, C,
+                                                                       torch.cuda.current_stream().cuda_stream), "cast_t")
+                e2 = (param._version, w, wt)
+                self._bf16_cache[key] = e2
+            return e2[1], e2[2]
+        if ent[0]._version != ent[3]:
+            self._refresh_pairs(st)
         return ent[1], ent[2]
+
+    def _pairs_state(self):
+        """Persistent 16-bit (W, W^T) buffers + device descriptor table of every block GEMM weight, per (precision, device)."""
+        dev = self.pos_embed_spatial.device
+        key = ("pairs", self.precision, dev)
+        st = self._bf16_cache.get(key)
+        if st is not None:
+            return st
+        import numpy as np
+        plist = []
+        for blk in self.blocks:
+            ws = [blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight]
+            if hasattr(blk, "proj_max_pool"):
+                ws.append(blk.proj_max_pool.weight)
+            plist += ws
+        L = self._lib()
+        dt = np.dtype([("src", "u8"), ("dst", "u8"), ("dst_t", "u8"), ("rows", "i4"), ("cols", "i4"), ("first", "i4"), ("pad", "i4")])
+        assert L.mvit_cast_desc_bytes() == dt.itemsize
+        by_id, rec, first = {}, [], 0
+        for p in plist:
+            R, C = p.shape
+            w = torch.empty(R, C, dtype=self._half_dtype(), device=dev)
+            wt = torch.empty(C, R, dtype=self._half_dtype(), device=dev)
+            by_id[id(p)] = [p, w, wt, -1]            # [param, W, W^T, version the copies were made from]
+            rec.append((p.data_ptr(), w.data_ptr(), wt.data_ptr(), R, C, first, 0))
+            first += ((R + 63) // 64) * ((C + 63) // 64)
+        table = torch.from_numpy(np.array(rec, dtype=dt).view(np.uint8).copy()).to(dev)
+        st = {"by_id": by_id, "table": table, "n": len(plist), "tiles": first, "ptrs": [p.data_ptr() for p in plist]}
+        self._bf16_cache[key] = st
+        return st
+
+    def _refresh_pairs(self, st):
+        ents = list(st["by_id"].values())
+        if [e[0].data_ptr() for e in ents] != st["ptrs"]:        # parameters were re-allocated (.to(), .cuda()): rebuild the table
+            del self._bf16_cache[("pairs", self.precision, self.pos_embed_spatial.device)]
+            st2 = self._pairs_state()
+            st.clear()
+            st.update(st2)
+            ents = list(st["by_id"].values())
+        _hip.check(self._lib().mvit_cast_transpose_multi(_hip.ptr(st["table"]), st["n"], st["tiles"],
+                                                         torch.cuda.current_stream().cuda_stream), "cast_multi")
+        for e in ents:
+            e[3] = e[0]._version
 
     def forward(self, x, bboxes=None, dataset_name=None, run_cross_proj=False, use_moco=False, moco_momentum=0.9,
                 return_logits=False):

@@ -234,6 +234,12 @@ int mvit_head_split_bwd(const void* dout, void* dqkv, int64_t ld, int chan_off, 
  * nn.Linear weight (attention.py:231,281, common.py:27-31 and their backward), refreshed together after an optimizer step. */
 int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int rows, int cols, void* stream);
 
+/* The same for a whole set of weights in one launch.  desc_table: device array of ntensors records of mvit_cast_desc_bytes() bytes
+ * {const float* src; void* dst; void* dst_t; int rows, cols; int first_tile, pad;} with first_tile = running sum of
+ * ceil(rows/64)*ceil(cols/64); total_tiles = that sum over all tensors (one workgroup per 64x64 tile). */
+int mvit_cast_desc_bytes(void);
+int mvit_cast_transpose_multi(const void* desc_table, int ntensors, int total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
