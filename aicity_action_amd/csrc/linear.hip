@@ -439,7 +439,7 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
 }
 
-template <typename TO>
+template <typename TO, bool RES, bool SCALE>     // RES / SCALE are compile-time for the fp32 output (straight-line epilogue)
 __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
@@ -490,12 +490,29 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
 
     // acc[mb][nb]: rows (registers) = n = 96*wn + 32*nb + (i&3) + 8*(i>>2) + 4*h ; column (lane) = m = 64*wm + 32*mb + r
     f32x16 acc[2][3];
+    if (sizeof(TO) == 4 && (epilogue & MVIT_EPI_BIAS)) {
+        // fp32 output: the bias is the accumulator's initial value (wave-uniform scalar loads, no vector load in the epilogue)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+        for (int nb = 0; nb < 3; ++nb) {
+            const float4* bp = reinterpret_cast<const float4*>(bias + n0 + 96 * wn + 32 * nb);
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 lo = bp[2 * g4], hi = bp[2 * g4 + 1];
+                const float b0 = h ? hi.x : lo.x, b1 = h ? hi.y : lo.y, b2 = h ? hi.z : lo.z, b3 = h ? hi.w : lo.w;
+                acc[0][nb][4 * g4 + 0] = b0; acc[1][nb][4 * g4 + 0] = b0;
+                acc[0][nb][4 * g4 + 1] = b1; acc[1][nb][4 * g4 + 1] = b1;
+                acc[0][nb][4 * g4 + 2] = b2; acc[1][nb][4 * g4 + 2] = b2;
+                acc[0][nb][4 * g4 + 3] = b3; acc[1][nb][4 * g4 + 3] = b3;
+            }
+        }
+    } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     uint32_t lds_x[4], lds_w[4];       // per-lane LDS byte addresses of the k-step fragments in buffer 0
 #pragma unroll
@@ -547,7 +564,45 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         if (t == 12345.678f) y[0] = (TO)0;
         return;
     }
-    // ---- epilogue from registers: lane = output row, quads of 4 consecutive columns ---------------------
+    if constexpr (sizeof(TO) == 4) {
+        // fp32 output: y = residual + scale * gelu?(acc) with the bias already inside acc.  Straight-line code: the twelve 16-byte
+        // residual loads of a 32-row block are all in flight before the first add (the runtime-flag version waited vmcnt(0)
+        // after every single load); the GELU flag and the ragged-M mask are decided once, outside the unrolled loops.
+        auto emit = [&](auto full_tag, auto gelu_tag) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                int64_t m = m0 + 64 * wm + 32 * mb + r;
+                const bool ok = decltype(full_tag)::value || m < M;
+                m = ok ? m : M - 1;
+                float sc = 1.f;
+                if (SCALE) sc = row_scale[m / rows_per_scale];
+                float4 rr[3][4];
+                if (RES) {
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rr[nb][q] = load4(residual + m * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+                }
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+                        if (decltype(gelu_tag)::value) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+                        if (SCALE) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                        if (RES) { v.x += rr[nb][q].x; v.y += rr[nb][q].y; v.z += rr[nb][q].z; v.w += rr[nb][q].w; }
+                        if (ok) *reinterpret_cast<float4*>(y + m * ldy + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q) = v;
+                    }
+            }
+        };
+        if (epilogue & MVIT_EPI_GELU) {
+            if (full_m) emit(std::true_type{}, std::true_type{}); else emit(std::false_type{}, std::true_type{});
+        } else {
+            if (full_m) emit(std::true_type{}, std::false_type{}); else emit(std::false_type{}, std::false_type{});
+        }
+        return;
+    }
+    // ---- 16-bit output, epilogue from registers: lane = output row, quads of 4 consecutive columns -----------
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int64_t m = m0 + 64 * wm + 32 * mb + r;
@@ -600,23 +655,40 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     }
 }
 
-template <typename TO>
-static int launch_linear_big(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
-                             int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
-                             int K, int epi, hipStream_t st) {
+template <typename TO, bool RES, bool SCALE>
+static int launch_linear_big_t(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+                               int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                               int K, int epi, hipStream_t st) {
     const int64_t nwg = ((M + G_BM - 1) / G_BM) * (N / G_BN);
     if (nwg > 0x7fffffff) return MVIT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO, RES, SCALE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((linear_big_kernel<TO>), dim3((unsigned)nwg), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+    hipLaunchKernelGGL((linear_big_kernel<TO, RES, SCALE>), dim3((unsigned)nwg), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
                        (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+
+template <typename TO>
+static int launch_linear_big(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+                             int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                             int K, int epi, hipStream_t st) {
+#define BIGL(R, S) return launch_linear_big_t<TO, R, S>(a, lda, w, bias, residual, ldr, row_scale, rps, y, ldy, M, N, K, epi, st)
+    if constexpr (sizeof(TO) == 4) {
+        const bool res = (epi & MVIT_EPI_RESIDUAL) != 0, scl = row_scale != nullptr;
+        if (res && scl) BIGL(true, true);
+        if (res) BIGL(true, false);
+        if (scl) BIGL(false, true);
+        BIGL(false, false);
+    } else {
+        BIGL(false, false);         // 16-bit output keeps the run-time flags (rare: only with a drop-path scale on a 16-bit result)
+    }
+#undef BIGL
 }
 
 // ------------------------------------------------------------------------------------------------
