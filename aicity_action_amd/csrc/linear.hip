@@ -186,31 +186,46 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(
             }
         }
         __syncthreads();
-        if (e_on) {
+        // rows -> global: flags decided once, residual loads of all of this thread's rows in flight before the first add
+        auto emit = [&](auto res_tag, auto scale_tag, auto full_tag) {
+            constexpr bool RES = decltype(res_tag)::value, SCL = decltype(scale_tag)::value, FULL = decltype(full_tag)::value;
+            constexpr int NR = 128 / RPI;
+            float4 rr[RES ? NR : 1][RES ? CWO / 4 : 1];
+            if (RES) {
 #pragma unroll
-            for (int i = 0; i < 128 / RPI; ++i) {
+                for (int i = 0; i < NR; ++i) {
+                    const int row = erow + RPI * i;
+                    int64_t m = m0 + (row >> 5) * (32 * WM) + 32 * mb + (row & 31);
+                    m = (FULL || m < M) ? m : M - 1;
+#pragma unroll
+                    for (int e = 0; e < CWO; e += 4) rr[RES ? i : 0][RES ? e / 4 : 0] = load4(residual + m * ldr + n0 + CWO * ec + e);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
                 const int row = erow + RPI * i;
                 // stage row (32*wave' + l) holds tile row 32*WM*wave' + 32*mb + l
                 const int64_t m = m0 + (row >> 5) * (32 * WM) + 32 * mb + (row & 31);
-                if (full_m || m < M) {
-                    float v[CWO];
+                const bool ok = FULL || m < M;
+                float v[CWO];
+#pragma unroll
+                for (int e = 0; e < CWO; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(stage + row * L_STAGE_LD + CWO * ec + e);
+                    v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                }
+                if (SCL) {
+                    const float sc = row_scale[(ok ? m : M - 1) / rows_per_scale];
+#pragma unroll
+                    for (int e = 0; e < CWO; ++e) v[e] *= sc;
+                }
+                if (RES) {
 #pragma unroll
                     for (int e = 0; e < CWO; e += 4) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(stage + row * L_STAGE_LD + CWO * ec + e);
-                        v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+                        const float4 r4 = rr[RES ? i : 0][RES ? e / 4 : 0];
+                        v[e] += r4.x; v[e + 1] += r4.y; v[e + 2] += r4.z; v[e + 3] += r4.w;
                     }
-                    if (row_scale) {
-                        const float sc = row_scale[m / rows_per_scale];
-#pragma unroll
-                        for (int e = 0; e < CWO; ++e) v[e] *= sc;
-                    }
-                    if (epilogue & MVIT_EPI_RESIDUAL) {
-#pragma unroll
-                        for (int e = 0; e < CWO; e += 4) {
-                            const float4 rr = load4(residual + m * ldr + n0 + CWO * ec + e);
-                            v[e] += rr.x; v[e + 1] += rr.y; v[e + 2] += rr.z; v[e + 3] += rr.w;
-                        }
-                    }
+                }
+                if (ok) {
                     TO* dst = y + m * ldy + n0 + CWO * ec;
                     if constexpr (sizeof(TO) == 2) {
                         uint4 o;
@@ -222,6 +237,17 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(
                     }
                 }
             }
+        };
+        if (e_on) {
+            const bool res = (epilogue & MVIT_EPI_RESIDUAL) != 0, scl = row_scale != nullptr;
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+#define EMIT3(R, S) { if (full_m) emit(R{}, S{}, T_{}); else emit(R{}, S{}, F_{}); }
+            if (res && scl) EMIT3(T_, T_)
+            else if (res) EMIT3(T_, F_)
+            else if (scl) EMIT3(F_, T_)
+            else EMIT3(F_, F_)
+#undef EMIT3
         }
     }
 }
