@@ -321,23 +321,30 @@ __global__ __launch_bounds__(256) void maxpool_skip_idx_kernel(const float* __re
         const int xo = (int)(tok % Wo); tok /= Wo;
         const int yo = (int)(tok % Ho);
         const int64_t bt = tok / Ho;
+        // nine unconditional loads at clamped coordinates (all in flight together); out-of-frame taps are then excluded from the
+        // arg-max scan by the validity mask, so the recorded position is the first maximum among the in-frame taps (ATen order)
+        float4 v[9];
+        bool ok9[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yi0 = 2 * yo + ky - 1;
+            const int yi = yi0 < 0 ? 0 : (yi0 >= H ? H - 1 : yi0);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xi0 = 2 * xo + kx - 1;
+                const int xi = xi0 < 0 ? 0 : (xi0 >= W ? W - 1 : xi0);
+                ok9[ky * 3 + kx] = yi0 == yi && xi0 == xi;
+                v[ky * 3 + kx] = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
+            }
+        }
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         uint32_t bx = 0, by = 0, bz = 0, bw = 0;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yi = 2 * yo + ky - 1;
-            if (yi < 0 || yi >= H) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int xi = 2 * xo + kx - 1;
-                if (xi < 0 || xi >= W) continue;
-                const uint32_t w = ky * 3 + kx;
-                const float4 v = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
-                if (v.x > m.x) { m.x = v.x; bx = w; }
-                if (v.y > m.y) { m.y = v.y; by = w; }
-                if (v.z > m.z) { m.z = v.z; bz = w; }
-                if (v.w > m.w) { m.w = v.w; bw = w; }
-            }
+        for (uint32_t w = 0; w < 9; ++w) {
+            if (ok9[w] && v[w].x > m.x) { m.x = v[w].x; bx = w; }
+            if (ok9[w] && v[w].y > m.y) { m.y = v[w].y; by = w; }
+            if (ok9[w] && v[w].z > m.z) { m.z = v[w].z; bz = w; }
+            if (ok9[w] && v[w].w > m.w) { m.w = v[w].w; bw = w; }
         }
         store4(y + i * 4, m);
         idx[i] = bx | (by << 8) | (bz << 16) | (bw << 24);

@@ -241,18 +241,25 @@ __global__ __launch_bounds__(256) void maxpool_skip_kernel(const float* __restri
         const int xo = (int)(tok % Wo); tok /= Wo;
         const int yo = (int)(tok % Ho);
         const int64_t bt = tok / Ho;
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        // all nine window loads are issued unconditionally at clamped coordinates (taps outside the frame re-read an in-frame
+        // element of the same window, which cannot change the maximum); with `continue` on the bounds tests every load sat
+        // behind its own branch + vmcnt(0)
+        float4 v[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const int yi = 2 * yo + dy - 1;
-            if (yi < 0 || yi >= H) continue;
+            int yi = 2 * yo + dy - 1;
+            yi = yi < 0 ? 0 : (yi >= H ? H - 1 : yi);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int xi = 2 * xo + dx - 1;
-                if (xi < 0 || xi >= W) continue;
-                const float4 v = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                int xi = 2 * xo + dx - 1;
+                xi = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
+                v[dy * 3 + dx] = load4(x + (((bt * H + yi) * W + xi) * C4 + c4) * 4);
             }
+        }
+        float4 m = v[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
         }
         store4(y + i * 4, m);
     }
