@@ -52,41 +52,49 @@ __global__ __launch_bounds__(256) void pool_conv_ln_kernel(const TA* __restrict_
             for (int dy = 0; dy < 3; ++dy) {
                 const int yi = yo * s + dy - 1;
                 if (yi < 0 || yi >= H) continue;
+                // the three dx taps of this row: loads issued together at clamped x (taps outside the frame are zeroed after
+                // the load) -- with `continue` on the x test every 16-byte load sat behind its own branch and vmcnt(0)
+                const TA* rowp = base + (((int64_t)ti * H + yi) * W) * ld;
+                float xv[3][NCH * CW];
+                float msk[3];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int xi = xo * s + dx - 1;
-                    if (xi < 0 || xi >= W) continue;
-                    const TA* p = base + (((int64_t)ti * H + yi) * W + xi) * ld;
-                    const float* wt = wsm + ((dt * 3 + dy) * 3 + dx) * 96;
+                    const int xi0 = xo * s + dx - 1;
+                    const int xi = xi0 < 0 ? 0 : (xi0 >= W ? W - 1 : xi0);
+                    msk[dx] = xi0 == xi ? 1.f : 0.f;
+                    const TA* p = rowp + (int64_t)xi * ld;
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) {
                         const int c0 = CW * (j + 4 * i);
                         if constexpr (sizeof(TA) == 2) {
                             float4 lo, hi;
                             load8(p + c0, lo, hi);
-                            const float4 w0 = *reinterpret_cast<const float4*>(wt + c0);
-                            const float4 w1 = *reinterpret_cast<const float4*>(wt + c0 + 4);
-                            acc[i * 8 + 0] = fmaf(lo.x, w0.x, acc[i * 8 + 0]);
-                            acc[i * 8 + 1] = fmaf(lo.y, w0.y, acc[i * 8 + 1]);
-                            acc[i * 8 + 2] = fmaf(lo.z, w0.z, acc[i * 8 + 2]);
-                            acc[i * 8 + 3] = fmaf(lo.w, w0.w, acc[i * 8 + 3]);
-                            acc[i * 8 + 4] = fmaf(hi.x, w1.x, acc[i * 8 + 4]);
-                            acc[i * 8 + 5] = fmaf(hi.y, w1.y, acc[i * 8 + 5]);
-                            acc[i * 8 + 6] = fmaf(hi.z, w1.z, acc[i * 8 + 6]);
-                            acc[i * 8 + 7] = fmaf(hi.w, w1.w, acc[i * 8 + 7]);
+                            xv[dx][i * 8 + 0] = lo.x; xv[dx][i * 8 + 1] = lo.y; xv[dx][i * 8 + 2] = lo.z; xv[dx][i * 8 + 3] = lo.w;
+                            xv[dx][i * 8 + 4] = hi.x; xv[dx][i * 8 + 5] = hi.y; xv[dx][i * 8 + 6] = hi.z; xv[dx][i * 8 + 7] = hi.w;
                         } else {
                             const float4 v = load4(p + c0);
-                            const float4 w0 = *reinterpret_cast<const float4*>(wt + c0);
-                            acc[i * 4 + 0] = fmaf(v.x, w0.x, acc[i * 4 + 0]);
-                            acc[i * 4 + 1] = fmaf(v.y, w0.y, acc[i * 4 + 1]);
-                            acc[i * 4 + 2] = fmaf(v.z, w0.z, acc[i * 4 + 2]);
-                            acc[i * 4 + 3] = fmaf(v.w, w0.w, acc[i * 4 + 3]);
+                            xv[dx][i * 4 + 0] = v.x; xv[dx][i * 4 + 1] = v.y; xv[dx][i * 4 + 2] = v.z; xv[dx][i * 4 + 3] = v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* wt = wsm + ((dt * 3 + dy) * 3 + dx) * 96;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const int c0 = CW * (j + 4 * i);
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(wt + c0 + e);
+                            acc[i * CW + e + 0] = fmaf(xv[dx][i * CW + e + 0] * msk[dx], w0.x, acc[i * CW + e + 0]);
+                            acc[i * CW + e + 1] = fmaf(xv[dx][i * CW + e + 1] * msk[dx], w0.y, acc[i * CW + e + 1]);
+                            acc[i * CW + e + 2] = fmaf(xv[dx][i * CW + e + 2] * msk[dx], w0.z, acc[i * CW + e + 2]);
+                            acc[i * CW + e + 3] = fmaf(xv[dx][i * CW + e + 3] * msk[dx], w0.w, acc[i * CW + e + 3]);
                         }
                     }
                 }
             }
         }
-        // LayerNorm over the 96 channels of this token (4 lanes x 24)
         float sum = 0.f;
 #pragma unroll
         for (int e = 0; e < 24; ++e) sum += acc[e];
