@@ -65,23 +65,43 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__
             for (int dy = 0; dy < 3; ++dy) {
                 const int yi = yo * s + dy - 1;
                 if (yi < 0 || yi >= H) continue;
+                // the three dx taps of this row: 16-byte loads issued together at clamped x, out-of-frame taps zeroed afterwards
+                const TA* rowp = base + (((int64_t)ti * H + yi) * W) * ld;
+                float xv[3][NCH * CW];
+                float msk[3];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int xi = xo * s + dx - 1;
-                    if (xi < 0 || xi >= W) continue;
-                    const TA* p = base + (((int64_t)ti * H + yi) * W + xi) * ld;
+                    const int xi0 = xo * s + dx - 1;
+                    const int xi = xi0 < 0 ? 0 : (xi0 >= W ? W - 1 : xi0);
+                    msk[dx] = xi0 == xi ? 1.f : 0.f;
+                    const TA* p = rowp + (int64_t)xi * ld;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const int c0 = CW * (j + 4 * i);
+                        if constexpr (sizeof(TA) == 2) {
+                            float4 lo, hi;
+                            load8(p + c0, lo, hi);
+                            xv[dx][i * 8 + 0] = lo.x; xv[dx][i * 8 + 1] = lo.y; xv[dx][i * 8 + 2] = lo.z; xv[dx][i * 8 + 3] = lo.w;
+                            xv[dx][i * 8 + 4] = hi.x; xv[dx][i * 8 + 5] = hi.y; xv[dx][i * 8 + 6] = hi.z; xv[dx][i * 8 + 7] = hi.w;
+                        } else {
+                            const float4 v = load4(p + c0);
+                            xv[dx][i * 4 + 0] = v.x; xv[dx][i * 4 + 1] = v.y; xv[dx][i * 4 + 2] = v.z; xv[dx][i * 4 + 3] = v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
                     const float* wt = wsm + ((dt * 3 + dy) * 3 + dx) * 96;
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) {
                         const int c0 = CW * (j + 4 * i);
 #pragma unroll
                         for (int e = 0; e < CW; e += 4) {
-                            const float4 v = load4(p + c0 + e);
                             const float4 ww = *reinterpret_cast<const float4*>(wt + c0 + e);
-                            acc[i * CW + e] = fmaf(v.x, ww.x, acc[i * CW + e]);
-                            acc[i * CW + e + 1] = fmaf(v.y, ww.y, acc[i * CW + e + 1]);
-                            acc[i * CW + e + 2] = fmaf(v.z, ww.z, acc[i * CW + e + 2]);
-                            acc[i * CW + e + 3] = fmaf(v.w, ww.w, acc[i * CW + e + 3]);
+                            acc[i * CW + e] = fmaf(xv[dx][i * CW + e] * msk[dx], ww.x, acc[i * CW + e]);
+                            acc[i * CW + e + 1] = fmaf(xv[dx][i * CW + e + 1] * msk[dx], ww.y, acc[i * CW + e + 1]);
+                            acc[i * CW + e + 2] = fmaf(xv[dx][i * CW + e + 2] * msk[dx], ww.z, acc[i * CW + e + 2]);
+                            acc[i * CW + e + 3] = fmaf(xv[dx][i * CW + e + 3] * msk[dx], ww.w, acc[i * CW + e + 3]);
                         }
                     }
                 }
