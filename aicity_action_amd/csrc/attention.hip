@@ -281,6 +281,330 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_bf16_kernel(const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (4 waves x 32 queries): inside one wave the score MFMAs of tile t+1 are issued between the
+// exponentials of tile t, and the running-max reduction of tile t+1 between the P.V MFMAs of tile t, so the matrix pipe
+// and the VALU of a SIMD both have work from ONE wave (the two co-resident waves of different workgroups then fill each
+// other's remaining gaps).  K runs one tile ahead of V: separate 3-deep LDS rings, K waves load tile t+3 while V waves
+// load tile t+2, both with one older load still in flight behind the counted wait.
+// ------------------------------------------------------------------------------------------------
+#define AP_RING (3 * A_KT * A_ROWB)      // one ring (K or V): 3 x 12 KiB
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_rd128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+#ifndef ATT_ABL
+#define ATT_ABL 0      // timing ablations of tools/ab_attn_abl.sh (results invalid when non-zero)
+#endif
+#define AP_WAIT6(N, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"((ATT_ABL & 64) ? 15 : N))
+
+template <bool ADD_Q>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+                                                               float* __restrict__ LSE, int heads, int Lq, int Lk,
+                                                               float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring 36 KiB | V ring 36 KiB
+    constexpr int NW = 4, PW = 6;
+
+    int qtile, bh;
+    xcd_group_map(qtile, bh);
+    const int b = bh / heads, g = bh - b * heads;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qtile * (A_QW * NW) + wave * A_QW;
+
+    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
+    const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
+
+    int qi = q0 + r;
+    const bool q_ok = qi < Lq;
+    qi = q_ok ? qi : Lq - 1;
+    bf16x8 qf[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
+
+    const bool is_v = wave >= NW / 2;                       // wave-uniform: waves 0,1 move K tiles, waves 2,3 V tiles
+    const char* src_bh = reinterpret_cast<const char*>(is_v ? Vb : Kb);
+    // piece i of this wave covers LDS positions p = 64*(PW*(wave&1) + i) + lane of the 12-KiB tile image: row p/12, 16-B slot
+    // p%12, which holds source chunk (slot - rot(row)) mod 12 for K (rotation swizzle on the SOURCE address) and chunk = slot
+    // for V.  Pieces i and i+3 are exactly 16 rows apart (same rotation), so three lane offsets + an immediate serve all six.
+    auto piece_off = [&](int i, int ln, int last_row) -> uint32_t {
+        const int p = 64 * (PW * (wave & 1) + i) + ln;
+        int row = p / 12, c = p - row * 12;
+        if (!is_v) {
+            c -= (row >> 2) & 3;
+            c = c < 0 ? c + 12 : c;
+        }
+        row = row < last_row ? row : last_row;
+        return (uint32_t)(row * 12 + c) * 16u;
+    };
+    uint32_t g_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g_off[i] = piece_off(i, lane, A_KT);
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem);
+    const uint32_t ring_a = smem_a + (is_v ? AP_RING : 0) + 1024 * (PW * (wave & 1));
+    // the DMA is issued as inline asm (SGPR base + 32-bit lane offset, LDS base in M0): through the builtin the compiler keeps
+    // 64-bit lane addresses in registers across the loop, spills them, and waits vmcnt(0) on the reloads between the pieces
+    auto dma1 = [&](const char* base, uint32_t off, uint32_t lds) {
+        // (M0 cannot be named as a clobber; nothing else in this kernel depends on it: gfx9+ LDS instructions do not read M0)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(off), "s"(base) : "memory");
+    };
+    auto dma = [&](int tile, int stage) {
+        const int k0 = tile * A_KT;
+        const char* t_base = src_bh + (int64_t)k0 * A_ROWB;   // wave-uniform
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_a + stage * (A_KT * A_ROWB));
+        if (k0 + A_KT <= Lk) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dma1(t_base, g_off[i], dst + 1024 * i);
+                dma1(t_base + 16 * A_ROWB, g_off[i], dst + 1024 * (i + 3));
+            }
+        } else {        // tail tile: rows past Lk re-read the last valid row (finite data; their scores are masked to -inf)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));      // keeps this rare path's address arithmetic inside the branch (not hoisted into loop-long registers)
+#pragma unroll
+            for (int i = 0; i < PW; ++i) dma1(t_base, piece_off(i, ln, Lk - 1 - k0), dst + 1024 * i);
+        }
+    };
+
+    // K fragment of k-step ks: row r, 16-B chunk (2ks + h + rot(r)) mod 12 with rot <= 3: k-steps 0..3 never wrap (immediate
+    // offsets from one lane address), k-steps 4 and 5 each get their own
+    uint32_t ka0, ka4, ka5;
+    {
+        const int p0 = h + ((r >> 2) & 3);
+        const int p4 = p0 + 8 >= 12 ? p0 + 8 - 12 : p0 + 8, p5 = p0 + 10 >= 12 ? p0 + 10 - 12 : p0 + 10;
+        ka0 = smem_a + r * A_ROWB + p0 * 16;
+        ka4 = smem_a + r * A_ROWB + p4 * 16;
+        ka5 = smem_a + r * A_ROWB + p5 * 16;
+    }
+    const int i16 = lane & 15, gi = lane >> 4;
+    const uint32_t va0 = smem_a + AP_RING + (4 * h + (i16 >> 2)) * A_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+
+    f32x16 o[3];
+#pragma unroll
+    for (int db = 0; db < 3; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m_run, l_run = 0.f;
+
+    const int nkt = (Lk + A_KT - 1) / A_KT;
+    // prologue loads: K tiles 0,1,2 / V tiles 0,1
+    dma(0, 0);
+    if (nkt > 1) dma(1, 1);
+    if (!is_v && nkt > 2) dma(2, 2);
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]));
+
+    // masks keys >= Lk of the (last) tile kt in a score tile, then the row maximum over the tile (both wave halves)
+    auto tile_max = [&](f32x16 (&s)[2], int kt) -> float {
+        const int kbase = kt * A_KT;
+        if (kbase + A_KT > Lk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    s[kb][i] = key < Lk ? s[kb][i] : -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+
+#define AP_KRD(KF, KS, KA, OFF) if (!(ATT_ABL & 32)) { KF[KS][0] = lds_rd128<OFF>(KA); KF[KS][1] = lds_rd128<OFF + 32 * A_ROWB>(KA); }
+#define AP_VTR(VL, VH, S16, DB, VA) if (!(ATT_ABL & 32)) VL[3 * (S16 & 1) + DB] = lds_tr16<S16 * 16 * A_ROWB + DB * 64>(VA); if (!(ATT_ABL & 32)) VH[3 * (S16 & 1) + DB] = lds_tr16<S16 * 16 * A_ROWB + DB * 64 + 8 * A_ROWB>(VA);
+#define AP_EXP(S, KB, SH) if (ATT_ABL & 1) { \
+        uint4 u_ = make_uint4(__float_as_uint(S[KB][8 * SH]), __float_as_uint(S[KB][8 * SH + 2]), __float_as_uint(S[KB][8 * SH + 4]), __float_as_uint(S[KB][8 * SH + 6])); \
+        pf[2 * KB + SH] = *reinterpret_cast<bf16x8*>(&u_); } else { \
+        uint32_t pk_[4]; \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) { \
+            const f32x2 sv_ = {S[KB][8 * SH + 2 * jj], S[KB][8 * SH + 2 * jj + 1]}; \
+            const f32x2 t_ = __builtin_elementwise_fma(sv_, c2, mc2); \
+            const f32x2 pp_ = {__builtin_amdgcn_exp2f(t_[0]), __builtin_amdgcn_exp2f(t_[1])}; \
+            ps2 += pp_; \
+            pk_[jj] = pack_bf16x2(pp_[0], pp_[1]); \
+        } \
+        uint4 u_ = make_uint4(pk_[0], pk_[1], pk_[2], pk_[3]); \
+        pf[2 * KB + SH] = *reinterpret_cast<bf16x8*>(&u_); }
+// scheduling pattern for a region of NM MFMAs: NV VALU instructions after each MFMA (the rest follow the last one)
+#define AP_MIX(NM, NV) _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0); }
+#define AP_PV(VL, VH, S16) _Pragma("unroll") for (int db = 0; db < 3; ++db) { \
+        const bf16x4 lo_ = VL[3 * (S16 & 1) + db], hi_ = VH[3 * (S16 & 1) + db]; \
+        bf16x8 vf_; \
+        vf_[0] = lo_[0]; vf_[1] = lo_[1]; vf_[2] = lo_[2]; vf_[3] = lo_[3]; vf_[4] = hi_[0]; vf_[5] = hi_[1]; vf_[6] = hi_[2]; vf_[7] = hi_[3]; \
+        if (!(ATT_ABL & 16)) o[db] = mfma16(vf_, pf[S16], o[db]); }
+
+    int kst = 0, vst = 0;     // ring stage of K tile kt+1 / V tile kt (set below)
+    f32x16 sa[2], sb[2];
+    {   // ---- prologue: S(0) and its row maximum --------------------------------------------------
+        if (nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8 kf[6][2];
+        AP_KRD(kf, 0, ka0, 0) AP_KRD(kf, 1, ka0, 32) AP_KRD(kf, 2, ka0, 64) AP_KRD(kf, 3, ka0, 96) AP_KRD(kf, 4, ka4, 0) AP_KRD(kf, 5, ka5, 0)
+        AP_WAIT6(0, kf[0][0], kf[0][1], kf[1][0], kf[1][1], kf[2][0], kf[2][1]);
+        asm volatile("" : "+v"(kf[3][0]), "+v"(kf[3][1]), "+v"(kf[4][0]), "+v"(kf[4][1]), "+v"(kf[5][0]), "+v"(kf[5][1]));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[kb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sa[kb] = mfma16(kf[ks][kb], qf[ks], sa[kb]);
+        m_run = tile_max(sa, 0);
+        kst = 1;
+    }
+
+    // one tile: P(kt) from `cur`, O += V(kt)^T P(kt); with NEXT also S(kt+1) -> `nx` and the running-max update
+    auto step = [&](f32x16 (&cur)[2], f32x16 (&nx)[2], int kt, auto next_tag) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        // K(kt+1) (K waves) / V(kt) (V waves) landed once at most the newest load of this wave is outstanding
+        if (ATT_ABL & 128) {}
+        else if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(ATT_ABL & 4)) __builtin_amdgcn_s_barrier();
+        {   // refill the stage everyone has left: K tile kt+3 replaces K(kt), V tile kt+2 replaces V(kt-1)
+            const int t_new = kt + (is_v ? 2 : 3);
+            if (!(ATT_ABL & 2) && t_new < nkt) dma(t_new, is_v ? (vst == 0 ? 2 : vst - 1) : (kst == 0 ? 2 : kst - 1));
+        }
+        const uint32_t k_base = kst * (A_KT * A_ROWB), v_addr = va0 + vst * (A_KT * A_ROWB);
+        kst = kst == 2 ? 0 : kst + 1;
+        vst = vst == 2 ? 0 : vst + 1;
+
+        const f32x2 c2 = {scale_log2e, scale_log2e};
+        const float mcs = -m_run * scale_log2e;
+        const f32x2 mc2 = {mcs, mcs};
+        f32x2 ps2 = {0.f, 0.f};
+        bf16x8 pf[4];
+        bf16x8 kf[3][2];
+        bf16x4 vl[6], vh[6];
+        // LDS reads return in order: each region requests the operands of the NEXT matrix region, then waits (counted) for its own
+        // R0: K(kt+1) k-steps 0..2 requested; first 16 keys of P
+        if (NEXT) {
+            const uint32_t a0 = ka0 + k_base;
+            AP_KRD(kf, 0, a0, 0) AP_KRD(kf, 1, a0, 32) AP_KRD(kf, 2, a0, 64)
+        }
+        AP_EXP(cur, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        // R1: V(kt) keys 0..15 requested; S(kt+1) k-steps 0..2 beside the next 16 keys of P
+        AP_VTR(vl, vh, 0, 0, v_addr) AP_VTR(vl, vh, 0, 1, v_addr) AP_VTR(vl, vh, 0, 2, v_addr)
+        if (NEXT) {
+            AP_WAIT6(6, kf[0][0], kf[0][1], kf[1][0], kf[1][1], kf[2][0], kf[2][1]);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nx[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) if (!(ATT_ABL & 8)) nx[kb] = mfma16(kf[ks][kb], qf[ks], nx[kb]);
+        }
+        AP_EXP(cur, 0, 1)
+        if (NEXT) { AP_MIX(6, 3) }
+        __builtin_amdgcn_sched_barrier(0);
+        // R2: V keys 16..31 and K(kt+1) k-steps 3..5 requested; O += V^T P over keys 0..31 beside the third 16 keys of P
+        AP_VTR(vl, vh, 1, 0, v_addr) AP_VTR(vl, vh, 1, 1, v_addr) AP_VTR(vl, vh, 1, 2, v_addr)
+        if (NEXT) {
+            AP_KRD(kf, 0, ka0 + k_base, 96) AP_KRD(kf, 1, ka4 + k_base, 0) AP_KRD(kf, 2, ka5 + k_base, 0)
+            AP_WAIT6(12, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
+        } else {
+            AP_WAIT6(6, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
+        }
+        AP_PV(vl, vh, 0)
+        if (NEXT) AP_WAIT6(6, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+        else AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+        AP_PV(vl, vh, 1)
+        AP_EXP(cur, 1, 0)
+        AP_MIX(6, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        // R3: V(kt) keys 32..47 requested; S(kt+1) k-steps 3..5 beside the last 16 keys of P
+        AP_VTR(vl, vh, 2, 0, v_addr) AP_VTR(vl, vh, 2, 1, v_addr) AP_VTR(vl, vh, 2, 2, v_addr)
+        if (NEXT) {
+            AP_WAIT6(6, kf[0][0], kf[0][1], kf[1][0], kf[1][1], kf[2][0], kf[2][1]);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) if (!(ATT_ABL & 8)) nx[kb] = mfma16(kf[ks][kb], qf[ks + 3], nx[kb]);
+        }
+        AP_EXP(cur, 1, 1)
+        if (NEXT) { AP_MIX(6, 3) }
+        __builtin_amdgcn_sched_barrier(0);
+        // R4: V keys 48..63 requested; O += V^T P over keys 32..63 beside the row maximum of S(kt+1)
+        AP_VTR(vl, vh, 3, 0, v_addr) AP_VTR(vl, vh, 3, 1, v_addr) AP_VTR(vl, vh, 3, 2, v_addr)
+        AP_WAIT6(6, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
+        AP_PV(vl, vh, 2)
+        AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+        AP_PV(vl, vh, 3)
+        float mx = 0.f;
+        if (NEXT) mx = tile_max(nx, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        l_run += ps2[0] + ps2[1];
+        if (NEXT) {
+            const float m_new = fmaxf(m_run, mx);
+            if (__any(m_new > m_run)) {        // rescale only when some query's running max moved
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < 3; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                m_run = m_new;
+            }
+        }
+    };
+
+    {
+        const int nfull = nkt - 1;          // tiles that have a successor
+        int kt = 0;
+        for (; kt + 2 <= nfull; kt += 2) {
+            step(sa, sb, kt, std::true_type{});
+            step(sb, sa, kt + 1, std::true_type{});
+        }
+        if (kt < nfull) {
+            step(sa, sb, kt, std::true_type{});
+            step(sb, sa, kt + 1, std::false_type{});
+        } else {
+            step(sa, sb, kt, std::false_type{});
+        }
+    }
+#undef AP_KRD
+#undef AP_VTR
+#undef AP_EXP
+#undef AP_PV
+#undef AP_MIX
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (LSE && q_ok && h == 0) LSE[(int64_t)bh * Lq + qi] = m_run * scale_log2e + __builtin_amdgcn_logf(l_tot);  // log2 domain
+    if (q_ok) {
+        const int C = heads * 96;
+        bf16_t* orow = O + ((int64_t)b * Lq + qi) * C + g * 96;
+        const bf16_t* qrow = Qb + (int64_t)qi * 96;
+#pragma unroll
+        for (int db = 0; db < 3; ++db)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int d = 32 * db + 8 * i4 + 4 * h;
+                float4 v = make_float4(o[db][4 * i4 + 0] * inv, o[db][4 * i4 + 1] * inv, o[db][4 * i4 + 2] * inv,
+                                       o[db][4 * i4 + 3] * inv);
+                if (ADD_Q) {
+                    const float4 qq = load4(qrow + d);
+                    v.x += qq.x; v.y += qq.y; v.z += qq.z; v.w += qq.w;
+                }
+                store4(orow + d, v);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32 path: one query per thread, 32-key tiles in LDS (broadcast reads).
 // ------------------------------------------------------------------------------------------------
 #define F_KT 32
@@ -372,6 +696,22 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
     hipStream_t st = as_stream(stream);
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (act_dtype == MVIT_BF16) {
+        static const bool pipe_env = !(getenv("MVIT_ATT_PIPE") && atoi(getenv("MVIT_ATT_PIPE")) == 0);   // default: software-pipelined kernel
+        if (pipe_env) {
+            dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
+            const float sl2 = scale * 1.44269504088896340736f;
+            static bool pattr_done = false;
+            if (!pattr_done) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess)
+                    return MVIT_ELAUNCH;
+                pattr_done = true;
+            }
+            if (add_q) hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), grid, dim3(256), 2 * AP_RING, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
+            else hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), grid, dim3(256), 2 * AP_RING, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
+            MVIT_LAUNCH_CHECK();
+            return MVIT_OK;
+        }
         static const int nw_env = getenv("MVIT_ATT_WAVES") ? atoi(getenv("MVIT_ATT_WAVES")) : 4;
         const int NWr = nw_env == 8 ? 8 : 4;
         dim3 grid((Lq + 32 * NWr - 1) / (32 * NWr), B * heads);
