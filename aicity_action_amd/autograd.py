@@ -248,9 +248,16 @@ class _BlockFn(torch.autograd.Function):
             r_full = pool_idx        # the backward only needs the argmax positions
         y = hx.linear(o, hx.w(at.proj.weight), at.proj.bias, torch.float32, residual=r, row_scale=dp1, rps=Lq)
         vn = hx.ln_fwd(y, blk.norm2)
-        pre = hx.linear(vn, hx.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, adt)
-        hid = torch.empty_like(pre)
-        _hip.check(L.mvit_gelu_fwd(_hip.ptr(pre), _hip.ptr(hid), pre.numel(), act, _st()), "gelu")
+        if act == _hip.BF16:      # fc1 + GELU in one GEMM pass: the pre-activation (kept for the backward) and the activation
+            w1 = hx.w(blk.mlp.fc1.weight)
+            pre = torch.empty(Mq, w1.shape[0], dtype=adt, device=dev)
+            hid = torch.empty_like(pre)
+            _hip.check(L.mvit_linear_gelu_fwd(_hip.ptr(vn), w1.shape[1], _hip.ptr(w1), _hip.ptr(blk.mlp.fc1.bias),
+                                              _hip.ptr(pre), _hip.ptr(hid), Mq, w1.shape[0], w1.shape[1], act, _st()), "fc1+gelu")
+        else:
+            pre = hx.linear(vn, hx.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, adt)
+            hid = torch.empty_like(pre)
+            _hip.check(L.mvit_gelu_fwd(_hip.ptr(pre), _hip.ptr(hid), pre.numel(), act, _st()), "gelu")
         out = hx.linear(hid, hx.w(blk.mlp.fc2.weight), blk.mlp.fc2.bias, torch.float32, residual=y, row_scale=dp2, rps=Lq)
         ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, addq
         ctx.saved = (x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2)

@@ -751,13 +751,14 @@ static int launch_linear_big(const void* a, int64_t lda, const void* w, const fl
 // tile start), which leaves the common epilogues (bias, bias+GELU) free of vector loads: the stores trail and the
 // next slab wait uses vmcnt(#stores) instead of vmcnt(0).
 // ------------------------------------------------------------------------------------------------
-template <typename TO, bool GELU>   // bias (optional) [+ GELU]; no residual / row scale (those use linear_big_kernel)
+// GELU: 0 = bias only, 1 = bias + GELU, 2 = both (16-bit out): y = GELU(pre) and y2 = pre, the pair a training step keeps
+template <typename TO, int GELU>   // no residual / row scale (those use linear_big_kernel)
 __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
-    const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
+    TO* __restrict__ y2, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
     TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = sizeof(TO) == 4 ? 24 : 12;     // vector stores per wave per full tile
+    constexpr int NST = (sizeof(TO) == 4 ? 24 : 12) * (GELU == 2 ? 2 : 1);     // vector stores per wave per full tile
 
     const int ntn = N / G_BN;
     const int nt = (int)((M + G_BM - 1) / G_BM) * ntn;
@@ -897,9 +898,22 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
                 const int nbase = n0 + 96 * wn + 32 * nb + 4 * h;    // + 8*q
                 float4 v[4];
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
+                for (int qd = 0; qd < 4; ++qd)
                     v[qd] = make_float4(acc[mb][nb][4 * qd], acc[mb][nb][4 * qd + 1], acc[mb][nb][4 * qd + 2], acc[mb][nb][4 * qd + 3]);
-                    if (GELU) {
+                if constexpr (GELU == 2 && sizeof(TO) == 2) {       // the pre-activation first, same 16-B pieces
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd += 2) {
+                        uint32_t a0 = pack_bf16x2(v[qd].x, v[qd].y), a1 = pack_bf16x2(v[qd].z, v[qd].w);
+                        uint32_t b0 = pack_bf16x2(v[qd + 1].x, v[qd + 1].y), b1 = pack_bf16x2(v[qd + 1].z, v[qd + 1].w);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (ok) *reinterpret_cast<uint4*>(y2 + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (qd + h)) = o;
+                    }
+                }
+                if (GELU) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
                         v[qd].x = gelu_fast(v[qd].x); v[qd].y = gelu_fast(v[qd].y);
                         v[qd].z = gelu_fast(v[qd].z); v[qd].w = gelu_fast(v[qd].w);
                     }
@@ -930,8 +944,8 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     }
 }
 
-template <typename TO, bool GELU>
-static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
+template <typename TO, int GELU>
+static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, void* y2,
                               int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
                               int K, int epi, hipStream_t st) {
     const int64_t nt = ((M + G_BM - 1) / G_BM) * (N / G_BN);
@@ -946,7 +960,7 @@ static int launch_linear_pers(const void* a, int64_t lda, const void* w, const f
     const int64_t q = (nt + 7) / 8;
     const int per = (int)(q < 64 ? q : 64);             // 2 workgroups per CU x 32 CUs per XCD
     hipLaunchKernelGGL((linear_pers_kernel<TO, GELU>), dim3((unsigned)(8 * per)), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
-                       (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
+                       (const bf16_t*)w, bias, (TO*)y2, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -1075,9 +1089,9 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         // one-tile-per-workgroup form overlaps them better)
         static const bool pers_env = getenv("MVIT_GEMM_NO_PERS") == nullptr;
         const bool use_pers = pers_env && !row_scale && !(epilogue & MVIT_EPI_RESIDUAL);
-#define PERS(TO, G) return launch_linear_pers<TO, G>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
-        if (use_pers && out_dtype == MVIT_BF16) { if (epilogue & MVIT_EPI_GELU) PERS(bf16_t, true); else PERS(bf16_t, false); }
-        if (use_pers && out_dtype == MVIT_F32) { if (epilogue & MVIT_EPI_GELU) PERS(float, true); else PERS(float, false); }
+#define PERS(TO, G) return launch_linear_pers<TO, G>(a, lda, w, bias, nullptr, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
+        if (use_pers && out_dtype == MVIT_BF16) { if (epilogue & MVIT_EPI_GELU) PERS(bf16_t, 1); else PERS(bf16_t, 0); }
+        if (use_pers && out_dtype == MVIT_F32) { if (epilogue & MVIT_EPI_GELU) PERS(float, 1); else PERS(float, 0); }
 #undef PERS
         if (out_dtype == MVIT_BF16)
             return launch_linear_big<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
@@ -1096,4 +1110,21 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
     if (a_dtype == MVIT_F32 && out_dtype == MVIT_BF16) DISPATCH(float, bf16_t);
 #undef DISPATCH
     return MVIT_EDTYPE;
+}
+
+// fc1 of the MLP in a training step: pre = a . w^T + bias and y = GELU(pre) from ONE pass over the accumulators (the backward
+// needs pre, the forward continues with y).  16-bit operands / outputs; shapes the persistent kernel does not cover run the
+// plain GEMM followed by the element-wise kernel.
+extern "C" int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
+extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, const float* bias, void* pre, void* y, int64_t M,
+                                    int N, int K, int act_dtype, void* stream) {
+    if (!a || !w || !bias || !pre || !y || M < 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (M == 0) return MVIT_OK;
+    static const bool fused = getenv("MVIT_GEMM_NO_PERS") == nullptr && getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
+    if (fused && N % G_BN == 0 && K % G_BK == 0 && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
+        return launch_linear_pers<bf16_t, 2>(a, lda, w, bias, pre, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
+    const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, bias, nullptr, 0, nullptr, 0, pre, MVIT_BF16, N, M, N, K, MVIT_EPI_BIAS, act_dtype, stream);
+    if (rc != MVIT_OK) return rc;
+    return mvit_gelu_fwd(pre, y, M * (int64_t)N, act_dtype, stream);
 }

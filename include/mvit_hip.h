@@ -126,6 +126,11 @@ int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int 
 
 /* erf-GELU as separate elementwise passes (training keeps the pre-activation; slowfast/models/common.py:28). */
 int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
+/* fc1 of the MLP in a training step (mlp.fc1 + GELU, reference slowfast/models/common.py:27-31 inside the autograd graph of
+ * tools/train_net.py): pre = a . w^T + bias AND y = GELU(pre) from one pass over the accumulators; pre is what the backward
+ * keeps.  16-bit operands/outputs only ([M][K] a with row stride lda, [N][K] w, [M][N] pre and y). */
+int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, const float* bias, void* pre, void* y, int64_t M, int N,
+                         int K, int act_dtype, void* stream);
 int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
 
 /* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight) and, when db != NULL, db[n] += sum_m dy[m][n]

@@ -125,6 +125,26 @@ def test_linear_persistent_many_tiles(hip_lib, epi):
         _close(y, ref.cpu(), 1e-2 if out_bf16 else 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 150 + 40, 768, 192), (700, 384, 96), (4096, 1536, 384)])
+def test_linear_gelu_dual_output(hip_lib, M, N, K):
+    """fc1 of a training step: one GEMM pass writes the pre-activation and GELU(pre) (persistent kernel; K=96 takes the
+    plain GEMM + element-wise route).  pre must equal the bias-only GEMM bit for bit; y = GELU of the fp32 accumulator."""
+    a = _rnd(M, K, seed=31).to(torch.bfloat16).to(DEV)
+    w = _rnd(N, K, seed=32, scale=0.08).to(torch.bfloat16).to(DEV)
+    bias = _rnd(N, seed=33, scale=0.2).to(DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty_like(pre)
+    _hip.check(hip_lib.mvit_linear_gelu_fwd(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(pre), _hip.ptr(y), M, N, K,
+                                            _hip.BF16, _st()))
+    plain = torch.empty_like(pre)
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(a), _hip.BF16, K, _hip.ptr(w), _hip.ptr(bias), None, N, None, 0, _hip.ptr(plain),
+                                       _hip.BF16, N, M, N, K, _hip.EPI_BIAS, _hip.BF16, _st()))
+    assert torch.equal(pre, plain)
+    ref = a.float() @ w.float().t() + bias
+    _close(pre, ref.cpu(), 1e-2)
+    _close(y, F.gelu(ref).cpu(), 1e-2)
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
