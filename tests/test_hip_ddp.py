@@ -80,3 +80,68 @@ def test_ddp_two_ranks_average_equals_full_batch():
         worst = max(worst, err)
     print("DDP(2 ranks) vs full batch: worst relative grad error %.2e" % worst)
     assert worst <= 1e-3
+
+
+def _rccl_worker(port, q):
+    """world_size 1 over the REAL "nccl" (= RCCL) backend: the communicator, DDP's bucket streams and the fused optimizer run
+    exactly as in `bench.py --gpus N` (one rank per GPU is all this box can offer)."""
+    import torch.distributed as dist
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.solver import construct_optimizer, soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    z, meta = load_golden("tiny_even")
+    out = {}
+    for tag in ("plain", "ddp"):
+        cfg = cfg_for_case(meta, "bf16", train=True)
+        cfg.NUM_GPUS = 1
+        model = build_model(cfg, gpu_id=0).train()
+        load_synth_weights(model, 0)
+        core = model
+        if tag == "ddp":
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0)
+        opt = construct_optimizer(model, cfg)
+        clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+        labels = torch.from_numpy(z["train.labels"]).cuda()
+        losses = []
+        for _ in range(3):
+            torch.manual_seed(7)                      # same drop-path / dropout draws in both runs
+            opt.set_lr(1e-3)
+            loss = soft_target_cross_entropy(model([clip]), labels)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                            # one explicit RCCL collective on this stream
+        torch.cuda.synchronize()
+        assert float(t.sum()) == 4.0
+        out[tag] = (losses, {k: p.detach().float().cpu().numpy() for k, p in core.named_parameters()})
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_rccl_single_rank_matches_plain_training():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    (l0, p0), (l1, p1) = out["plain"], out["ddp"]
+    assert np.allclose(l0, l1, rtol=1e-3, atol=1e-5), (l0, l1)      # bit-equal until the first noise-sign flip (see below)
+    # Adam divides by sqrt(v): a parameter whose true gradient is zero (the k bias: softmax is shift-invariant) moves by +-lr on
+    # the sign of rounding noise, and the fp32 atomics of the weight-gradient kernels do not sum in a fixed order -- so single
+    # elements may differ by up to steps*lr between ANY two runs; the bulk must agree
+    worst = max(np.abs(p0[k] - p1[k]).max() for k in p0)
+    mean = sum(np.abs(p0[k] - p1[k]).sum() for k in p0) / sum(p0[k].size for k in p0)
+    print("RCCL DDP (1 rank) vs plain, 3 steps: losses", l1, "parameter difference worst %.2e mean %.2e" % (worst, mean))
+    assert worst <= 3 * 1e-3 * 1.01
+    assert mean <= 1e-5
