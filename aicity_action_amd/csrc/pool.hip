@@ -279,14 +279,38 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
             const int64_t orow = (((int64_t)bh * T + fo) * Ho * Wo + (int64_t)yo * Wo + xo) * 96;
             if (BWD) {
                 float dyv[24];
+                // unconditional loads at a clamped row (a bounds test per load makes the compiler wait after each one), masked after
+                const int64_t lrow = tok_ok ? orow : 0;
+                const float keep = tok_ok ? 1.f : 0.f;
+                if constexpr (S != 1) {                // stride-2 tiles: the batched form spills (measured slower); load piece by piece
 #pragma unroll
-                for (int i = 0; i < NCH; ++i)
+                    for (int i = 0; i < NCH; ++i)
 #pragma unroll
-                    for (int e = 0; e < CW; e += 4) {
-                        float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (tok_ok) d4 = load4(dout + orow + CW * (lj + 4 * i) + e);
-                        dyv[i * CW + e] = d4.x; dyv[i * CW + e + 1] = d4.y; dyv[i * CW + e + 2] = d4.z; dyv[i * CW + e + 3] = d4.w;
+                        for (int e = 0; e < CW; e += 4) {
+                            float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (tok_ok) d4 = load4(dout + orow + CW * (lj + 4 * i) + e);
+                            dyv[i * CW + e] = d4.x; dyv[i * CW + e + 1] = d4.y; dyv[i * CW + e + 2] = d4.z; dyv[i * CW + e + 3] = d4.w;
+                        }
+                } else if constexpr (sizeof(TA) == 2) {       // 16-bit: keep the six 8-byte pieces packed until all are requested
+                    uint2 raw[NCH * CW / 4];
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) raw[(i * CW + e) / 4] = *reinterpret_cast<const uint2*>(dout + lrow + CW * (lj + 4 * i) + e);
+#pragma unroll
+                    for (int k4 = 0; k4 < NCH * CW / 4; ++k4) {
+                        dyv[4 * k4] = lo16_to_f32(raw[k4].x) * keep; dyv[4 * k4 + 1] = hi16_to_f32(raw[k4].x) * keep;
+                        dyv[4 * k4 + 2] = lo16_to_f32(raw[k4].y) * keep; dyv[4 * k4 + 3] = hi16_to_f32(raw[k4].y) * keep;
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4) {
+                            const float4 d4 = load4(dout + lrow + CW * (lj + 4 * i) + e);
+                            dyv[i * CW + e] = d4.x * keep; dyv[i * CW + e + 1] = d4.y * keep; dyv[i * CW + e + 2] = d4.z * keep; dyv[i * CW + e + 3] = d4.w * keep;
+                        }
+                }
                 float c1 = 0.f, c2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i)
