@@ -300,7 +300,9 @@ __device__ __forceinline__ bf16x8 lds_rd128(uint32_t addr) {
 #endif
 #define AP_WAIT6(N, a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"((ATT_ABL & 64) ? 15 : N))
 
-template <bool ADD_Q>
+// SLOT: every MFMA of regions R1..R4 is followed by its own small bundle of softmax VALU work, pinned by scheduling barriers
+// (one exp2 pair = pk_fma, 2 exp, cvt_pk, pk_add per MFMA gap) instead of leaving the interleave to the compiler
+template <bool ADD_Q, bool SLOT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                                const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                                float* __restrict__ LSE, int heads, int Lq, int Lk,
@@ -432,6 +434,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
         } \
         uint4 u_ = make_uint4(pk_[0], pk_[1], pk_[2], pk_[3]); \
         pf[2 * KB + SH] = *reinterpret_cast<bf16x8*>(&u_); }
+#define AP_PAIR(S, KB, SH, JJ) { \
+        const f32x2 sv_ = {S[KB][8 * SH + 2 * JJ], S[KB][8 * SH + 2 * JJ + 1]}; \
+        const f32x2 t_ = __builtin_elementwise_fma(sv_, c2, mc2); \
+        const f32x2 pp_ = {__builtin_amdgcn_exp2f(t_[0]), __builtin_amdgcn_exp2f(t_[1])}; \
+        ps2 += pp_; \
+        pkw[2 * KB + SH][JJ] = pack_bf16x2(pp_[0], pp_[1]); }
+#define AP_PFIN(E) { uint4 u_ = make_uint4(pkw[E][0], pkw[E][1], pkw[E][2], pkw[E][3]); pf[E] = *reinterpret_cast<bf16x8*>(&u_); }
+#define AP_SB __builtin_amdgcn_sched_barrier(0);
+#define AP_PV1(VL, VH, S16, DB) { \
+        const bf16x4 lo_ = VL[3 * (S16 & 1) + DB], hi_ = VH[3 * (S16 & 1) + DB]; \
+        bf16x8 vf_; \
+        vf_[0] = lo_[0]; vf_[1] = lo_[1]; vf_[2] = lo_[2]; vf_[3] = lo_[3]; vf_[4] = hi_[0]; vf_[5] = hi_[1]; vf_[6] = hi_[2]; vf_[7] = hi_[3]; \
+        o[DB] = mfma16(vf_, pf[S16], o[DB]); }
+#define AP_MX4(I0) mx = fmaxf(fmaxf(mx, nx[0][I0]), nx[1][I0]); mx = fmaxf(fmaxf(mx, nx[0][I0 + 1]), nx[1][I0 + 1]); \
+        mx = fmaxf(fmaxf(mx, nx[0][I0 + 2]), nx[1][I0 + 2]); mx = fmaxf(fmaxf(mx, nx[0][I0 + 3]), nx[1][I0 + 3]);
 // scheduling pattern for a region of NM MFMAs: NV VALU instructions after each MFMA (the rest follow the last one)
 #define AP_MIX(NM, NV) _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0); }
 #define AP_PV(VL, VH, S16) _Pragma("unroll") for (int db = 0; db < 3; ++db) { \
@@ -484,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
         const f32x2 mc2 = {mcs, mcs};
         f32x2 ps2 = {0.f, 0.f};
         bf16x8 pf[4];
+        uint32_t pkw[4][4];
         bf16x8 kf[3][2];
         bf16x4 vl[6], vh[6];
         // LDS reads return in order: each region requests the operands of the NEXT matrix region, then waits (counted) for its own
@@ -502,13 +520,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) nx[kb][i] = 0.f;
+            if constexpr (SLOT) {
+                nx[0] = mfma16(kf[0][0], qf[0], nx[0]); AP_PAIR(cur, 0, 1, 0) AP_SB
+                nx[1] = mfma16(kf[0][1], qf[0], nx[1]); AP_PAIR(cur, 0, 1, 1) AP_SB
+                nx[0] = mfma16(kf[1][0], qf[1], nx[0]); AP_PAIR(cur, 0, 1, 2) AP_SB
+                nx[1] = mfma16(kf[1][1], qf[1], nx[1]); AP_PAIR(cur, 0, 1, 3) AP_SB
+                nx[0] = mfma16(kf[2][0], qf[2], nx[0]); AP_SB
+                nx[1] = mfma16(kf[2][1], qf[2], nx[1]); AP_PFIN(1) AP_SB
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) if (!(ATT_ABL & 8)) nx[kb] = mfma16(kf[ks][kb], qf[ks], nx[kb]);
+            }
         }
-        AP_EXP(cur, 0, 1)
-        if (NEXT) { AP_MIX(6, 3) }
+        if (!(SLOT && NEXT)) { AP_EXP(cur, 0, 1) }
+        if (NEXT && !SLOT) { AP_MIX(6, 3) }
         __builtin_amdgcn_sched_barrier(0);
         // R2: V keys 16..31 and K(kt+1) k-steps 3..5 requested; O += V^T P over keys 0..31 beside the third 16 keys of P
         AP_VTR(vl, vh, 1, 0, v_addr) AP_VTR(vl, vh, 1, 1, v_addr) AP_VTR(vl, vh, 1, 2, v_addr)
@@ -518,33 +545,77 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
         } else {
             AP_WAIT6(6, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
         }
+        if constexpr (SLOT) {
+            AP_PV1(vl, vh, 0, 0) AP_PAIR(cur, 1, 0, 0) AP_SB
+            AP_PV1(vl, vh, 0, 1) AP_PAIR(cur, 1, 0, 1) AP_SB
+            AP_PV1(vl, vh, 0, 2) AP_PAIR(cur, 1, 0, 2) AP_SB
+            if (NEXT) AP_WAIT6(6, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+            else AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+            AP_PV1(vl, vh, 1, 0) AP_PAIR(cur, 1, 0, 3) AP_SB
+            AP_PV1(vl, vh, 1, 1) AP_SB
+            AP_PV1(vl, vh, 1, 2) AP_PFIN(2) AP_SB
+        } else {
         AP_PV(vl, vh, 0)
         if (NEXT) AP_WAIT6(6, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
         else AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
         AP_PV(vl, vh, 1)
         AP_EXP(cur, 1, 0)
         AP_MIX(6, 3)
+        }
         __builtin_amdgcn_sched_barrier(0);
         // R3: V(kt) keys 32..47 requested; S(kt+1) k-steps 3..5 beside the last 16 keys of P
         AP_VTR(vl, vh, 2, 0, v_addr) AP_VTR(vl, vh, 2, 1, v_addr) AP_VTR(vl, vh, 2, 2, v_addr)
         if (NEXT) {
             AP_WAIT6(6, kf[0][0], kf[0][1], kf[1][0], kf[1][1], kf[2][0], kf[2][1]);
+            if constexpr (SLOT) {
+                nx[0] = mfma16(kf[0][0], qf[3], nx[0]); AP_PAIR(cur, 1, 1, 0) AP_SB
+                nx[1] = mfma16(kf[0][1], qf[3], nx[1]); AP_PAIR(cur, 1, 1, 1) AP_SB
+                nx[0] = mfma16(kf[1][0], qf[4], nx[0]); AP_PAIR(cur, 1, 1, 2) AP_SB
+                nx[1] = mfma16(kf[1][1], qf[4], nx[1]); AP_PAIR(cur, 1, 1, 3) AP_SB
+                nx[0] = mfma16(kf[2][0], qf[5], nx[0]); AP_SB
+                nx[1] = mfma16(kf[2][1], qf[5], nx[1]); AP_PFIN(3) AP_SB
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) if (!(ATT_ABL & 8)) nx[kb] = mfma16(kf[ks][kb], qf[ks + 3], nx[kb]);
+            }
         }
-        AP_EXP(cur, 1, 1)
-        if (NEXT) { AP_MIX(6, 3) }
+        if (!(SLOT && NEXT)) { AP_EXP(cur, 1, 1) }
+        if (NEXT && !SLOT) { AP_MIX(6, 3) }
         __builtin_amdgcn_sched_barrier(0);
         // R4: V keys 48..63 requested; O += V^T P over keys 32..63 beside the row maximum of S(kt+1)
         AP_VTR(vl, vh, 3, 0, v_addr) AP_VTR(vl, vh, 3, 1, v_addr) AP_VTR(vl, vh, 3, 2, v_addr)
+        float mx = 0.f;
+        if constexpr (SLOT && NEXT) {
+            if ((kt + 2) * A_KT > Lk) {           // S(kt+1) is the (ragged) last tile: mask keys >= Lk (wave-uniform, once per kernel)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = (kt + 1) * A_KT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        nx[kb][i] = key < Lk ? nx[kb][i] : -INFINITY;
+                    }
+            }
+            AP_WAIT6(6, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
+            AP_PV1(vl, vh, 2, 0) AP_SB
+            AP_PV1(vl, vh, 2, 1) mx = fmaxf(nx[0][0], nx[1][0]); mx = fmaxf(fmaxf(mx, nx[0][1]), nx[1][1]); mx = fmaxf(fmaxf(mx, nx[0][2]), nx[1][2]); mx = fmaxf(fmaxf(mx, nx[0][3]), nx[1][3]); AP_SB
+            AP_PV1(vl, vh, 2, 2) AP_MX4(4) AP_SB
+            AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
+            AP_PV1(vl, vh, 3, 0) AP_MX4(8) AP_SB
+            AP_PV1(vl, vh, 3, 1) AP_MX4(12) AP_SB
+            AP_PV1(vl, vh, 3, 2)
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+        } else {
         AP_WAIT6(6, vl[0], vl[1], vl[2], vh[0], vh[1], vh[2]);
         AP_PV(vl, vh, 2)
         AP_WAIT6(0, vl[3], vl[4], vl[5], vh[3], vh[4], vh[5]);
         AP_PV(vl, vh, 3)
-        float mx = 0.f;
         if (NEXT) mx = tile_max(nx, kt + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         l_run += ps2[0] + ps2[1];
         if (NEXT) {
@@ -580,6 +651,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __r
 #undef AP_EXP
 #undef AP_PV
 #undef AP_MIX
+#undef AP_PAIR
+#undef AP_PFIN
+#undef AP_SB
+#undef AP_PV1
+#undef AP_MX4
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -710,15 +786,20 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
         if (pipe_env) {
             dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
             const float sl2 = scale * 1.44269504088896340736f;
+            static const bool slot_env = getenv("MVIT_ATT_SLOT") && atoi(getenv("MVIT_ATT_SLOT")) != 0;
             static bool pattr_done = false;
             if (!pattr_done) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess)
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess)
                     return MVIT_ELAUNCH;
                 pattr_done = true;
             }
-            if (add_q) hipLaunchKernelGGL((attn_fwd_pipe_kernel<true>), grid, dim3(256), 2 * AP_RING, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
-            else hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), grid, dim3(256), 2 * AP_RING, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2);
+#define PIPE_LAUNCH(AQ, SL) hipLaunchKernelGGL((attn_fwd_pipe_kernel<AQ, SL>), grid, dim3(256), 2 * AP_RING, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, lse, heads, Lq, Lk, sl2)
+            if (slot_env) { if (add_q) PIPE_LAUNCH(true, true); else PIPE_LAUNCH(false, true); }
+            else { if (add_q) PIPE_LAUNCH(true, false); else PIPE_LAUNCH(false, false); }
+#undef PIPE_LAUNCH
             MVIT_LAUNCH_CHECK();
             return MVIT_OK;
         }

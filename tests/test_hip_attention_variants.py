@@ -43,7 +43,7 @@ print("OK worst %%.2e" %% worst)
 """
 
 
-@pytest.mark.parametrize("env", [{"MVIT_ATT_PIPE": "0"}, {"MVIT_ATT_W64": "1"}, {}])
+@pytest.mark.parametrize("env", [{"MVIT_ATT_PIPE": "0"}, {"MVIT_ATT_W64": "1"}, {"MVIT_ATT_SLOT": "1"}, {}])
 def test_attention_forward_variant(env):
     e = dict(os.environ)
     e.update(env)
