@@ -40,6 +40,8 @@ def main():
         reps = int(a[4]) if len(a) > 4 else 20
         x = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        if os.environ.get("OPB_ZERO"):
+            x.zero_(); w.zero_()
         bias = torch.randn(N, device=dev)
         res = torch.randn(M, N, device=dev) if "r" in epi else None
         out_f32 = "r" in epi
@@ -59,6 +61,8 @@ def main():
         q = torch.randn(B, h, Lq, 96, device=dev).bfloat16()
         k = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
         v = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
+        if os.environ.get("OPB_ZERO"):       # all-zero operands: same instruction stream, far less switching power
+            q.zero_(); k.zero_(); v.zero_()
         o = torch.empty(B, Lq, h * 96, device=dev, dtype=torch.bfloat16)
 
         def fn():
