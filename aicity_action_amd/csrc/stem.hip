@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void stem_f32_kernel(const float* __restrict__
 //   two ds_read_b64 from a bf16 halo patch in LDS, no im2col buffer.
 //   One workgroup per CU walks 1x8x16-token tiles.  Waves 0-2 each own one 32-channel block with its
 //   whole 32x512 weight slab resident in 128 VGPRs (B fragments) and compute 128 tokens x 32 channels;
-//   wave 3 is the loader: it converts the next tile's fp32 halo patch to bf16 into the other LDS buffer
-//   while the MFMA waves run.  Output rows are written 128 B (32 fp32 channels) per half-wave with
+//   all four waves share the conversion of the NEXT tile's fp32 halo patch to bf16 into the other LDS buffer: the loads are
+//   requested before the MFMA work and converted after it.  Output rows are written 128 B (32 fp32 channels) per half-wave with
 //   bias + separable position embedding fused.
 // ------------------------------------------------------------------------------------------------
 #define SM_TY 8
@@ -100,6 +100,10 @@ __global__ __launch_bounds__(256) void stem_f32_kernel(const float* __restrict__
 #define SM_PATCH (9 * SM_PLANE)        // 45360
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4a __attribute__((ext_vector_type(4)));      // 16-byte aligned
+#ifndef STEM_ABL
+#define STEM_ABL 0     // timing ablations (tools): 1 no halo fill, 2 no MFMA loop, 4 no epilogue stores
+#endif
 
 __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restrict__ clip, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ pos_s,
@@ -130,46 +134,59 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
         }
     }
 
-    auto fill = [&](int tile, char* dst) {   // loader wave only
-        const int b = tile / (To * tiles_per_frame);
+    // Halo patch of a tile: 9 (ci,dt) planes x 35 rows x 68 px fp32 -> bf16 in LDS.  Every wave takes every 4th group of 3 rows
+    // (27 16-byte loads per lane).  The loads of the NEXT tile are requested before the MFMA work of the current one and
+    // converted / written to the other LDS buffer after it, so their latency hides under the matrix work.  Every load is an
+    // unconditional 16-byte load at a CLAMPED address (row and column), fixed up afterwards: with bounds tests around the loads
+    // the compiler waited for each one (and a single loader wave's 105 round trips per tile were 80 % of the kernel).
+    constexpr int FN = 27;
+    // 16-byte ALIGNED loads (a 16-byte load at a 4-byte-aligned address is split by the memory pipeline and was 4x slower): a lane
+    // loads image pixels [xa, xa+3], xa = 4*tx0 - 4 + 4*seg for 18 segments per row; the LDS piece j holds pixels xa_j+1 .. xa_j+4
+    // (patch pixel 0 = image pixel 4*tx0 - 3, which keeps the MFMA waves' 8-byte fragment reads aligned), i.e. elements 1..3 of the
+    // lane's quad and element 0 of the next lane's.  Rows and columns outside the image load a clamped address and are zeroed.
+    const bool lane_on = lane < 54;
+    const int rig = lane_on ? lane / 18 : 0, seg = lane_on ? lane - rig * 18 : 0;    // idle lanes shadow lane 0 (valid addresses)
+    auto tile_pos = [&](int tile, int& b, int& to, int& ty0, int& tx0) {
+        b = tile / (To * tiles_per_frame);
         int rem = tile - b * (To * tiles_per_frame);
-        const int to = rem / tiles_per_frame;
+        to = rem / tiles_per_frame;
         rem -= to * tiles_per_frame;
-        const int ty0 = (rem / tiles_x) * SM_TY, tx0 = (rem % tiles_x) * SM_TX;
-        const int rig = lane / 17, seg = lane - rig * 17;
-        const bool lane_on = lane < 51;
-        const int xs = 4 * tx0 - 3 + 4 * seg;
-        for (int rg0 = 0; rg0 < 105; rg0 += 35) {   // 3 batches of 35 16-byte loads in flight per lane
-            f4u v[35];
+        ty0 = (rem / tiles_x) * SM_TY;
+        tx0 = (rem % tiles_x) * SM_TX;
+    };
+    auto fill_issue = [&](int tile, f4u (&v)[FN], uint32_t& rmask) {
+        int b, to, ty0, tx0;
+        tile_pos(tile, b, to, ty0, tx0);
+        const int xa = 4 * tx0 - 4 + 4 * seg;
+        const bool xok = xa >= 0 && xa + 3 < S;
+        const int xc = xok ? xa : 0;
+        rmask = 0;
 #pragma unroll
-            for (int u = 0; u < 35; ++u) {
-                v[u] = (f4u){0.f, 0.f, 0.f, 0.f};
-                const int row = 3 * (rg0 + u) + rig;
-                if (lane_on && rg0 + u < 105) {
-                    const int p = row / SM_PH, py = row - p * SM_PH;
-                    const int ci = p / 3, dt = p - ci * 3;
-                    const int ti = 2 * to + dt - 1, yi = 4 * ty0 - 3 + py;
-                    if (ti >= 0 && ti < T && yi >= 0 && yi < S) {
-                        const float* src = clip + ((((int64_t)b * 3 + ci) * T + ti) * S + yi) * S;
-                        if (xs >= 0 && xs + 3 < S) {
-                            v[u] = *reinterpret_cast<const f4u*>(src + xs);
-                        } else {
+        for (int u = 0; u < FN; ++u) {
+            int rgi = 4 * u + wave;
+            rgi = rgi < 105 ? rgi : 104;
+            const int row = 3 * rgi + rig;
+            const int p = row / SM_PH, py = row - p * SM_PH;
+            const int ci = p / 3, dt = p - ci * 3;
+            const int ti = 2 * to + dt - 1, yi = 4 * ty0 - 3 + py;
+            if (xok && ti >= 0 && ti < T && yi >= 0 && yi < S) rmask |= 1u << u;
+            const int tc = ti < 0 ? 0 : (ti >= T ? T - 1 : ti), yc = yi < 0 ? 0 : (yi >= S ? S - 1 : yi);
+            v[u] = *reinterpret_cast<const f4a*>(clip + ((((int64_t)b * 3 + ci) * T + tc) * S + yc) * S + xc);
+        }
+    };
+    auto fill_commit = [&](int tile, f4u (&v)[FN], uint32_t rmask, char* dst) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (xs + e >= 0 && xs + e < S) v[u][e] = src[xs + e];
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 35; ++u) {
-                const int row = 3 * (rg0 + u) + rig;
-                if (lane_on && rg0 + u < 105) {
-                    uint2 o;
-                    o.x = pack_bf16x2(v[u][0], v[u][1]);
-                    o.y = pack_bf16x2(v[u][2], v[u][3]);
-                    *reinterpret_cast<uint2*>(dst + row * SM_ROWB + 8 * seg) = o;
-                }
+        for (int u = 0; u < FN; ++u) {
+            const int rgi = 4 * u + wave;
+            const int row = 3 * rgi + rig;
+            const float keep = ((rmask >> u) & 1) ? 1.f : 0.f;
+            const float f0 = v[u][0] * keep, f1 = v[u][1] * keep, f2 = v[u][2] * keep, f3 = v[u][3] * keep;
+            const float nx0 = __shfl_down(f0, 1, 64);          // first pixel of the next segment of the same row
+            if (lane_on && seg < 17 && rgi < 105) {
+                uint2 o;
+                o.x = pack_bf16x2(f1, f2);
+                o.y = pack_bf16x2(f3, nx0);
+                *reinterpret_cast<uint2*>(dst + row * SM_ROWB + 8 * seg) = o;
             }
         }
     };
@@ -180,13 +197,18 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
     const float bias_v = (wave < 3) ? bias[32 * wave + r] : 0.f;
 
     int tile = blockIdx.x;
-    if (wave == 3 && tile < ntiles) fill(tile, patch[0]);
+    f4u fv[FN];
+    uint32_t fmask = 0;
+    if (!(STEM_ABL & 1) && tile < ntiles) {
+        fill_issue(tile, fv, fmask);
+        fill_commit(tile, fv, fmask, patch[0]);
+    }
     __syncthreads();
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        if (wave == 3) {
-            if (tile + (int)gridDim.x < ntiles) fill(tile + gridDim.x, patch[buf ^ 1]);
-        } else {
+        const bool more = !(STEM_ABL & 1) && tile + (int)gridDim.x < ntiles;
+        if (more) fill_issue(tile + gridDim.x, fv, fmask);      // lands under the MFMA work below
+        if (wave < 3) {
             const char* pb = patch[buf] + a_base;
             f32x16 acc[4];
 #pragma unroll
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int s = 0; s < ((STEM_ABL & 2) ? 1 : 32); ++s) {
                 const int row0 = 2 * s;                       // tap row of lane-half 0
                 const int c0 = (row0 / 7) * SM_PLANE + (row0 % 7) * SM_ROWB;
                 int off = c0;
@@ -219,18 +241,28 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
             const int ty0 = (rem / tiles_x) * SM_TY, tx0 = (rem % tiles_x) * SM_TX;
             const int c = 32 * wave + r;
             const float add_t = bias_v, pt = pos_t[to * 96 + c];
+            // the 16 position-embedding loads of an m-block are all requested (at clamped token positions) before the first add:
+            // a bounds test around each load made the compiler wait for every single one (64 round trips per tile, 4x the tile's MFMA time)
+            float* xt = x + ((int64_t)b * To + to) * So * So * 96 + c;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb) {
+                float ps[16];
+                int hwv[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int tl = (i & 3) + 8 * (i >> 2) + 4 * h;      // token within the m-block
                     const int yo = ty0 + 2 * mb + (tl >> 4), xo = tx0 + (tl & 15);
-                    if (yo < So && xo < So) {
-                        const int hw = yo * So + xo;
-                        x[(((int64_t)b * To + to) * So * So + hw) * 96 + c] = (acc[mb][i] + add_t) + (pos_s[(int64_t)hw * 96 + c] + pt);
-                    }
+                    const bool ok = yo < So && xo < So;
+                    const int hw = ok ? yo * So + xo : 0;
+                    hwv[i] = ok ? hw : -1;
+                    ps[i] = pos_s[(int64_t)hw * 96 + c];
                 }
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (hwv[i] >= ((STEM_ABL & 4) ? 1 << 30 : 0)) xt[(int64_t)hwv[i] * 96] = (acc[mb][i] + add_t) + (ps[i] + pt);
+            }
         }
+        if (more) fill_commit(tile + gridDim.x, fv, fmask, patch[buf ^ 1]);
         __syncthreads();
     }
 }

@@ -76,6 +76,18 @@ def main():
                                             _hip.BF16, st))
             t = lse.view(B * h, Lq)[:, :(Lq // 128) * 128].reshape(B * h, Lq // 128, 4, 32)[..., :8].float()
             print("phase cycles/tile (wait, barrier+dma, S+max, softmax, PV issue, -):", [round(x, 1) for x in t.mean(dim=(0, 1, 2)).tolist()], "sum", round(t.mean(dim=(0, 1, 2)).sum().item(), 1))
+    elif op == "stem":
+        B = int(a[0]); reps = int(a[1]) if len(a) > 1 else 20
+        clip = torch.randn(B, 3, 16, 448, 448, device=dev)
+        w = torch.randn(96, 3, 3, 7, 7, device=dev) * 0.05
+        bias = torch.randn(96, device=dev)
+        ps, pt = torch.randn(112 * 112, 96, device=dev), torch.randn(8, 96, device=dev)
+        x = torch.empty(B, 8 * 112 * 112, 96, device=dev)
+
+        def fn():
+            _hip.check(L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(ps), _hip.ptr(pt), _hip.ptr(x), B, 16, 448, _hip.BF16, st))
+        ms = timeit(fn, reps)
+        print("stem B=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s" % (B, ms * 1e3, B * 8.5e9 / ms / 1e9, (clip.numel() + x.numel()) * 4 / ms / 1e9))
     elif op == "wgrad":
         M, N, K = int(a[0]), int(a[1]), int(a[2])
         reps = int(a[3]) if len(a) > 3 else 20
