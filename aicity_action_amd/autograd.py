@@ -225,10 +225,15 @@ class _BlockFn(torch.autograd.Function):
             _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, _st()), "head_split")
         forked = L.mvit_side_fork(_st()) == 0          # k / v pooling convs beside the q one (independent readers of qkv)
         side = L.mvit_side_stream() if forked else _st()
+        pool_saved = {}     # which -> (xhat, rstd): what the LayerNorm backward needs, so the backward runs no second convolution
+        save_ln = os.environ.get("MVIT_POOL_RECOMPUTE", "0") != "1"
         for which, buf, conv, norm, stride in pools:
-            _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
-                                               _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W, stride, norm.eps, act,
-                                               _st() if which == 0 else side), "pool")
+            xh = torch.empty_like(buf) if save_ln else None
+            rs = torch.empty(buf.shape[0] * buf.shape[1] * buf.shape[2], dtype=torch.float32, device=dev) if save_ln else None
+            pool_saved[which] = (xh, rs)
+            _hip.check(L.mvit_pool_conv_ln_fwd_train(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
+                                                     _hip.ptr(norm.bias), _hip.ptr(buf), _hip.ptr(xh), _hip.ptr(rs), B, h, T, H, W, stride,
+                                                     norm.eps, act, _st() if which == 0 else side), "pool")
         if forked:
             _hip.check(L.mvit_side_join(_st()), "side_join")
         o = torch.empty(Mq, Cout, dtype=adt, device=dev)
@@ -261,6 +266,7 @@ class _BlockFn(torch.autograd.Function):
         out = hx.linear(hid, hx.w(blk.mlp.fc2.weight), blk.mlp.fc2.bias, torch.float32, residual=y, row_scale=dp2, rps=Lq)
         ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, addq
         ctx.saved = (x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2)
+        ctx.pool_saved = pool_saved
         return out.view(B, Lq, Cout)
 
     @staticmethod
@@ -269,6 +275,8 @@ class _BlockFn(torch.autograd.Function):
         L, act, adt = hx.L, hx.act, hx.adt
         x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2 = ctx.saved
         ctx.saved = None
+        pool_saved = ctx.pool_saved
+        ctx.pool_saved = None
         at = blk.attn
         dev = x2.device
         B = q.shape[0]
@@ -318,10 +326,11 @@ class _BlockFn(torch.autograd.Function):
             dw = hx.zeros(96, 1, 3, 3, 3)
             dgm = hx.zeros(96)
             dbt = hx.zeros(96)
-            _hip.check(L.mvit_pool_conv_ln_bwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
-                                               _hip.ptr(dbuf), _hip.ptr(dconv), _hip.ptr(d_qkv), _hip.ptr(dw), _hip.ptr(dgm),
-                                               _hip.ptr(dbt), 1, _hip.ptr(pws), B, h, T, H, W, stride, norm.eps, act, _st()),
-                       "pool_bwd")
+            xh, rs = pool_saved.get(which, (None, None))
+            _hip.check(L.mvit_pool_conv_ln_bwd_saved(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
+                                                     _hip.ptr(xh), _hip.ptr(rs), _hip.ptr(dbuf), _hip.ptr(dconv), _hip.ptr(d_qkv),
+                                                     _hip.ptr(dw), _hip.ptr(dgm), _hip.ptr(dbt), 1, _hip.ptr(pws), B, h, T, H, W, stride,
+                                                     norm.eps, act, _st()), "pool_bwd")
             pool_grads += [dw, dgm, dbt]
         dWqkv, dbqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
         d_u = hx.linear(d_qkv, hx.wt(at.qkv.weight), None, adt)

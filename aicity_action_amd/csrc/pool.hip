@@ -7,7 +7,8 @@
 template <typename TA>
 __global__ __launch_bounds__(256) void pool_conv_ln_kernel(const TA* __restrict__ qkv, int64_t ld, int chan_off,
                                                            const float* __restrict__ w, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, TA* __restrict__ out, int B,
+                                                           const float* __restrict__ beta, TA* __restrict__ out,
+                                                           TA* __restrict__ xhat, float* __restrict__ rstd_out, int B,
                                                            int heads, int T, int H, int W, int Ho, int Wo, int s,
                                                            float eps) {
     constexpr int CW = 16 / sizeof(TA);  // channels per 16-byte chunk (bf16: 8, fp32: 4)
@@ -112,6 +113,16 @@ __global__ __launch_bounds__(256) void pool_conv_ln_kernel(const TA* __restrict_
         const float rstd = 1.0f / sqrtf(sq * (1.0f / 96.0f) + eps);
         if (ok) {
             TA* o = out + it * 96;
+            if (xhat) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                    for (int q4 = 0; q4 < CW / 4; ++q4) {
+                        const int e = i * CW + q4 * 4;
+                        store4(xhat + it * 96 + CW * (j + 4 * i) + q4 * 4, make_float4(acc[e] * rstd, acc[e + 1] * rstd, acc[e + 2] * rstd, acc[e + 3] * rstd));
+                    }
+                if (j == 0) rstd_out[it] = rstd;
+            }
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int c0 = CW * (j + 4 * i);
@@ -343,6 +354,15 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
                 }
             } else if (tok_ok) {
                 TA* o = out + orow;
+                if (dout) {     // training forward: keep xhat (and rstd) so that the backward needs no second convolution
+                    TA* xh = const_cast<TA*>(dout) + orow;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4)
+                            store4(xh + CW * (lj + 4 * i) + e, make_float4(v[i * CW + e] * rstd, v[i * CW + e + 1] * rstd, v[i * CW + e + 2] * rstd, v[i * CW + e + 3] * rstd));
+                    if (lj == 0) part[orow / 96] = rstd;
+                }
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
                     const int c0 = CW * (lj + 4 * i);
@@ -418,7 +438,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
 
 template <typename TA, int S>
 static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
-                             const float* beta, void* out, int B, int heads, int T, int H, int W, int Ho, int Wo,
+                             const float* beta, void* out, void* xhat, float* rstd, int B, int heads, int T, int H, int W, int Ho, int Wo,
                              float eps, hipStream_t st) {
     using P = PoolTile<TA, S>;
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
@@ -430,7 +450,7 @@ static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const fl
         attr_done = true;
     }
     hipLaunchKernelGGL((pool_tiled_kernel<TA, S, false>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
-                       beta, (TA*)out, (const TA*)nullptr, (float*)nullptr, heads, T, H, W, Ho, Wo, eps);
+                       beta, (TA*)out, (const TA*)xhat, rstd, heads, T, H, W, Ho, Wo, eps);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -620,10 +640,12 @@ int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, c
     return rc < 0 ? rc : rows;
 }
 
-extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
-                                     const float* beta, void* out, int B, int heads, int T, int H, int W, int stride_hw,
-                                     float eps, int act_dtype, void* stream) {
-    if (!qkv || !w || !gamma || !beta || !out || B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0 || stride_hw <= 0)
+// Training forward: additionally keeps xhat = (conv - mean) * rstd ([B][heads][T*Ho*Wo][96], act-typed) and rstd (fp32 per token),
+// which is all the LayerNorm backward needs -- the backward then skips the second convolution (mvit_pool_conv_ln_bwd_saved).
+extern "C" int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                                           const float* beta, void* out, void* xhat, float* rstd, int B, int heads, int T, int H,
+                                           int W, int stride_hw, float eps, int act_dtype, void* stream) {
+    if (!qkv || !w || !gamma || !beta || !out || (xhat && !rstd) || B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0 || stride_hw <= 0)
         return MVIT_EINVAL;
     if ((ld & 7) || (chan_off & 7)) return MVIT_EUNSUPPORTED;
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
@@ -635,20 +657,27 @@ extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, 
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (stride_hw == 1 || stride_hw == 2) {
         if (act_dtype == MVIT_BF16) {
-            if (stride_hw == 1) return launch_pool_tiled<bf16_t, 1>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
-            return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+            if (stride_hw == 1) return launch_pool_tiled<bf16_t, 1>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
+            return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
         }
-        if (stride_hw == 1) return launch_pool_tiled<float, 1>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
-        return launch_pool_tiled<float, 2>(qkv, ld, chan_off, w, gamma, beta, out, B, heads, T, H, W, Ho, Wo, eps, st);
+        if (stride_hw == 1) return launch_pool_tiled<float, 1>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
+        return launch_pool_tiled<float, 2>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
     }
     if (act_dtype == MVIT_F32)
         hipLaunchKernelGGL((pool_conv_ln_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)qkv, ld,
-                           chan_off, w, gamma, beta, (float*)out, B, heads, T, H, W, Ho, Wo, stride_hw, eps);
+                           chan_off, w, gamma, beta, (float*)out, (float*)xhat, rstd, B, heads, T, H, W, Ho, Wo, stride_hw, eps);
     else if (act_dtype == MVIT_BF16)
         hipLaunchKernelGGL((pool_conv_ln_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)qkv, ld,
-                           chan_off, w, gamma, beta, (bf16_t*)out, B, heads, T, H, W, Ho, Wo, stride_hw, eps);
+                           chan_off, w, gamma, beta, (bf16_t*)out, (bf16_t*)xhat, rstd, B, heads, T, H, W, Ho, Wo, stride_hw, eps);
     else
         return MVIT_EDTYPE;
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+
+extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                                     const float* beta, void* out, int B, int heads, int T, int H, int W, int stride_hw,
+                                     float eps, int act_dtype, void* stream) {
+    return mvit_pool_conv_ln_fwd_train(qkv, ld, chan_off, w, gamma, beta, out, nullptr, nullptr, B, heads, T, H, W, stride_hw, eps,
+                                       act_dtype, stream);
 }

@@ -365,12 +365,100 @@ extern "C" int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H
     return (rows * 192 + wrows * 2592) * (int64_t)sizeof(float);
 }
 
+// LayerNorm backward of the pooling conv from what the training forward kept (xhat, rstd): one pass over rows of 96 channels,
+// 4 lanes per row.  d_conv = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial sums of d_gamma = sum dy*xhat
+// and d_beta = sum dy go to part[block][192].
+template <typename TA>
+__global__ __launch_bounds__(256) void pool_ln_bwd_saved_kernel(const TA* __restrict__ xhat, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const TA* __restrict__ dout,
+                                                                TA* __restrict__ dconv, float* __restrict__ part, int64_t total) {
+    constexpr int CW = 16 / sizeof(TA);
+    constexpr int NCH = 24 / CW;
+    __shared__ float red[192];
+    if (threadIdx.x < 192) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int j = threadIdx.x & 3;
+    float g[24], dg[24], db[24];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            g[i * CW + e] = gamma[CW * (j + 4 * i) + e];
+            dg[i * CW + e] = 0.f;
+            db[i * CW + e] = 0.f;
+        }
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < total; it0 += (int64_t)gridDim.x * 64) {
+        const int64_t it = it0 + (threadIdx.x >> 2);
+        const bool ok = it < total;
+        const int64_t itc = ok ? it : total - 1;
+        const float keep = ok ? 1.f : 0.f;
+        float xh[24], dy[24];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < CW; e += 4) {
+                const float4 a = load4(xhat + itc * 96 + CW * (j + 4 * i) + e);
+                const float4 d = load4(dout + itc * 96 + CW * (j + 4 * i) + e);
+                const int k = i * CW + e;
+                xh[k] = a.x; xh[k + 1] = a.y; xh[k + 2] = a.z; xh[k + 3] = a.w;
+                dy[k] = d.x * keep; dy[k + 1] = d.y * keep; dy[k + 2] = d.z * keep; dy[k + 3] = d.w * keep;
+            }
+        const float r = rstd[itc];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            dg[k] = fmaf(dy[k], xh[k], dg[k]);
+            db[k] += dy[k];
+            dy[k] *= g[k];
+            c1 += dy[k];
+            c2 = fmaf(dy[k], xh[k], c2);
+        }
+        c1 += __shfl_xor(c1, 1, 64); c1 += __shfl_xor(c1, 2, 64);
+        c2 += __shfl_xor(c2, 1, 64); c2 += __shfl_xor(c2, 2, 64);
+        c1 *= (1.0f / 96.0f);
+        c2 *= (1.0f / 96.0f);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < CW; e += 4) {
+                    const int k = i * CW + e;
+                    store4(dconv + it * 96 + CW * (j + 4 * i) + e,
+                           make_float4(r * (dy[k] - c1 - xh[k] * c2), r * (dy[k + 1] - c1 - xh[k + 1] * c2),
+                                       r * (dy[k + 2] - c1 - xh[k + 2] * c2), r * (dy[k + 3] - c1 - xh[k + 3] * c2)));
+                }
+        }
+    }
+    // block reduction: the 64 lanes that share (lane & 3) own the same 24 channels
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            const int c = CW * (j + 4 * i) + e;
+            float a = dg[i * CW + e], bsum = db[i * CW + e];
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) {       // lanes with the same j inside the wave
+                a += __shfl_xor(a, off, 64);
+                bsum += __shfl_xor(bsum, off, 64);
+            }
+            if ((threadIdx.x & 63) < 4) {
+                atomicAdd(&red[c], a);
+                atomicAdd(&red[96 + c], bsum);
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 192) part[(int64_t)blockIdx.x * 192 + threadIdx.x] = red[threadIdx.x];
+}
+
 // dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.
 // dw [96][27] fp32 is ACCUMULATED into (caller zeroes it once per step); dgamma/dbeta: accumulate flag.
-extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
-                                     const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
-                                     int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
-                                     int stride_hw, float eps, int act_dtype, void* stream) {
+// xhat / rstd (optional, from mvit_pool_conv_ln_fwd_train): when given, the LayerNorm backward is one row-wise pass over them
+// instead of a second convolution + statistics.
+extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                                           const void* xhat, const float* rstd, const void* dout, void* dconv, void* dqkv,
+                                           float* dw, float* dgamma, float* dbeta, int accumulate_param, float* workspace, int B,
+                                           int heads, int T, int H, int W, int stride_hw, float eps, int act_dtype, void* stream) {
+    if ((xhat != nullptr) != (rstd != nullptr)) return MVIT_EINVAL;
     if (!qkv || !w || !gamma || !dout || !dconv || !dqkv || !dw || !dgamma || !dbeta || !workspace || B <= 0 ||
         heads <= 0 || T <= 0 || H <= 0 || W <= 0 || stride_hw <= 0)
         return MVIT_EINVAL;
@@ -397,7 +485,17 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
 #define RUN(TA)                                                                                                            \
     SideStream* ss = nullptr;                                                                                              \
     hipStream_t sw = st;                                                                                                   \
-    if (tiled) {                                                                                                           \
+    if (xhat) {                                                                                                            \
+        int64_t bs = (tot_out + 63) / 64;       /* as many blocks as the workspace has partial rows for (>= PB_MAXBLK) */  \
+        bs = bs > prow ? prow : bs;                                                                                        \
+        bs = bs > 2048 ? 2048 : bs;                                                                                        \
+        hipLaunchKernelGGL((pool_ln_bwd_saved_kernel<TA>), dim3((unsigned)bs), dim3(256), 0, st, (const TA*)xhat, rstd, gamma, \
+                           (const TA*)dout, (TA*)dconv, workspace, tot_out);                                                \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+        ss = side_stream_for_current_device();                                                                             \
+        if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
+        { const int rr_ = launch_pool_reduce(workspace, (int)bs, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
+    } else if (tiled) {                                                                                                    \
         const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
                                                           H, W, stride_hw, eps, act_dtype, st);                            \
         if (nrows < 0) return nrows;                                                                                       \
@@ -433,4 +531,12 @@ extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, 
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN
     return MVIT_OK;
+}
+
+extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
+                                     const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
+                                     int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
+                                     int stride_hw, float eps, int act_dtype, void* stream) {
+    return mvit_pool_conv_ln_bwd_saved(qkv, ld, chan_off, w, gamma, nullptr, nullptr, dout, dconv, dqkv, dw, dgamma, dbeta,
+                                       accumulate_param, workspace, B, heads, T, H, W, stride_hw, eps, act_dtype, stream);
 }

@@ -165,6 +165,17 @@ int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float
                           int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
                           int stride_hw, float eps, int act_dtype, void* stream);
 
+/* Training pair that avoids the second convolution in the backward: the forward also writes xhat = (conv - mean) * rstd
+ * ([B][heads][T*Ho*Wo][96], act-typed) and rstd (fp32 per output token) -- what torch's native_layer_norm keeps for
+ * slowfast/models/attention.py:66-67 --; the backward takes them (or NULL, NULL = recompute as mvit_pool_conv_ln_bwd). */
+int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const float* beta,
+                                void* out, void* xhat, float* rstd, int B, int heads, int T, int H, int W, int stride_hw, float eps,
+                                int act_dtype, void* stream);
+int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* xhat,
+                                const float* rstd, const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma,
+                                float* dbeta, int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
+                                int stride_hw, float eps, int act_dtype, void* stream);
+
 /* Backward of mvit_maxpool_skip_fwd: gradient goes to the first maximum of each window (ATen semantics). */
 int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
 

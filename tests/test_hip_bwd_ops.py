@@ -204,6 +204,23 @@ def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
     _close(dw, w.grad.reshape(96, 27), tol)
     _close(dg, g.grad, tol)
     _close(db, b.grad, tol)
+    # the training pair: forward keeps xhat / rstd, backward runs the row-wise LayerNorm backward from them (no second conv)
+    bd = b.detach().to(DEV)
+    out2 = torch.empty(B, h, Lo, 96, dtype=adt, device=DEV)
+    xh = torch.empty(B, h, Lo, 96, dtype=adt, device=DEV)
+    rs = torch.empty(B * h * Lo, device=DEV)
+    _hip.check(hip_lib.mvit_pool_conv_ln_fwd_train(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd),
+                                                   _hip.ptr(out2), _hip.ptr(xh), _hip.ptr(rs), B, h, T, H, W, s, 1e-5, act, _st()))
+    _close(out2, out.detach(), 1e-2 if act else 2e-5)
+    dqkv2 = torch.zeros_like(dqkv)
+    dw2, dg2, db2 = torch.zeros(96, 27, device=DEV), torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+    _hip.check(hip_lib.mvit_pool_conv_ln_bwd_saved(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(xh), _hip.ptr(rs),
+                                                   _hip.ptr(dod), _hip.ptr(dconv), _hip.ptr(dqkv2), _hip.ptr(dw2), _hip.ptr(dg2),
+                                                   _hip.ptr(db2), 0, _hip.ptr(ws), B, h, T, H, W, s, 1e-5, act, _st()))
+    _close(dqkv2[:, :, which * C:(which + 1) * C], qkvr.grad[:, :, which * C:(which + 1) * C], tol)
+    _close(dw2, w.grad.reshape(96, 27), tol)
+    _close(dg2, g.grad, tol)
+    _close(db2, b.grad, tol)
 
 
 @pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 1, 5, 9, 96)])
