@@ -288,11 +288,18 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
         g16, gs, grps = hx.scaled16(d_out, dp2, Lq)
         dW2, db2 = hx.wgrad(hid, g16, Cout, 4 * Cout, gs, grps)
-        d_hid = hx.linear(g16, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=gs, rps=grps)
-        del g16
-        d_pre = torch.empty_like(d_hid)
-        _hip.check(L.mvit_gelu_bwd(_hip.ptr(pre), _hip.ptr(d_hid), _hip.ptr(d_pre), pre.numel(), act, _st()), "gelu_bwd")
-        del d_hid
+        if act == _hip.BF16:      # fc2 data gradient and the GELU backward in one GEMM pass
+            w2t = hx.wt(blk.mlp.fc2.weight)
+            d_pre = torch.empty_like(pre)
+            _hip.check(L.mvit_linear_dgelu_fwd(_hip.ptr(g16), g16.shape[1], _hip.ptr(w2t), _hip.ptr(gs), grps, _hip.ptr(pre), _hip.ptr(d_pre),
+                                               Mq, w2t.shape[0], w2t.shape[1], act, _st()), "fc2 dgrad + gelu_bwd")
+            del g16
+        else:
+            d_hid = hx.linear(g16, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=gs, rps=grps)
+            del g16
+            d_pre = torch.empty_like(d_hid)
+            _hip.check(L.mvit_gelu_bwd(_hip.ptr(pre), _hip.ptr(d_hid), _hip.ptr(d_pre), pre.numel(), act, _st()), "gelu_bwd")
+            del d_hid
         dW1, db1 = hx.wgrad(vn, d_pre, 4 * Cout, Cout)
         d_vn = hx.linear(d_pre, hx.wt(blk.mlp.fc1.weight), None, adt)
         del d_pre

@@ -50,6 +50,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one v_rcp;
 // libm erff costs 30-60 VALU instructions per element and made the fc1 epilogue VALU-bound.
+__device__ __forceinline__ float gelu_grad_fast(float x) {      // d/dx GELU_erf, same erf approximation, exponential shared
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
+}
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -491,7 +503,9 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
 }
 
-template <typename TO, bool RES, bool SCALE>     // RES / SCALE are compile-time for the fp32 output (straight-line epilogue)
+// DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
+// GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
+template <typename TO, bool RES, bool SCALE, bool DG = false>     // RES / SCALE are compile-time for the fp32 output (straight-line epilogue)
 __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
@@ -660,6 +674,14 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         const int64_t m = m0 + 64 * wm + 32 * mb + r;
         const bool ok = full_m || m < M;
         const float sc = (row_scale && ok) ? row_scale[m / rows_per_scale] : 1.f;
+        [[maybe_unused]] uint4 pre_raw[3][2];
+        if constexpr (DG) {     // the six 16-byte pieces of this row's pre-activation, in the OUTPUT piece layout, all requested first
+            const bf16_t* pre = reinterpret_cast<const bf16_t*>(residual) + (ok ? m : M - 1) * ldr + n0 + 96 * wn;
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) pre_raw[nb][qq] = *reinterpret_cast<const uint4*>(pre + 32 * nb + 8 * (2 * qq + h));
+        }
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
             const int nbase = n0 + 96 * wn + 32 * nb + 4 * h;    // + 8*q
@@ -676,6 +698,22 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                     v[q].z = gelu_fast(v[q].z); v[q].w = gelu_fast(v[q].w);
                 }
                 if (row_scale) { v[q].x *= sc; v[q].y *= sc; v[q].z *= sc; v[q].w *= sc; }
+            }
+            if constexpr (DG) {
+                // a piece holds columns 8q'..8q'+7 (q' = 2qq+h): the inverse of the store-side exchange hands every lane the
+                // pre-activations of its own quads q = 2qq and 2qq+1 (columns 8q + 4h .. +3)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const uint4 L = pre_raw[nb][qq];
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(L.x, L.z, false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
+                    float4& va = v[2 * qq];
+                    float4& vb = v[2 * qq + 1];
+                    va.x *= gelu_grad_fast(lo16_to_f32(t0[0])); va.y *= gelu_grad_fast(hi16_to_f32(t0[0]));
+                    va.z *= gelu_grad_fast(lo16_to_f32(t1[0])); va.w *= gelu_grad_fast(hi16_to_f32(t1[0]));
+                    vb.x *= gelu_grad_fast(lo16_to_f32(t0[1])); vb.y *= gelu_grad_fast(hi16_to_f32(t0[1]));
+                    vb.z *= gelu_grad_fast(lo16_to_f32(t1[1])); vb.w *= gelu_grad_fast(hi16_to_f32(t1[1]));
+                }
             }
             if constexpr (sizeof(TO) == 4) {
 #pragma unroll
@@ -707,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     }
 }
 
-template <typename TO, bool RES, bool SCALE>
+template <typename TO, bool RES, bool SCALE, bool DG = false>
 static int launch_linear_big_t(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
                                int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
                                int K, int epi, hipStream_t st) {
@@ -715,12 +753,12 @@ static int launch_linear_big_t(const void* a, int64_t lda, const void* w, const 
     if (nwg > 0x7fffffff) return MVIT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO, RES, SCALE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO, RES, SCALE, DG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((linear_big_kernel<TO, RES, SCALE>), dim3((unsigned)nwg), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+    hipLaunchKernelGGL((linear_big_kernel<TO, RES, SCALE, DG>), dim3((unsigned)nwg), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
                        (const bf16_t*)w, bias, residual, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
@@ -1127,4 +1165,23 @@ extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, c
     const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, bias, nullptr, 0, nullptr, 0, pre, MVIT_BF16, N, M, N, K, MVIT_EPI_BIAS, act_dtype, stream);
     if (rc != MVIT_OK) return rc;
     return mvit_gelu_fwd(pre, y, M * (int64_t)N, act_dtype, stream);
+}
+
+// Data gradient of fc2 fused with the GELU backward: y = GELU'(pre) * row_scale[m/rps] * (a . w^T), i.e. the gradient of fc1's
+// output straight from the GEMM (a = d_out rows in 16 bit, w = fc2.weight^T [N][K], pre / y [M][N] 16-bit).  Shapes the 128x192
+// kernel does not cover run the plain GEMM followed by the element-wise kernel.
+extern "C" int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
+extern "C" int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
+                                     const void* pre, void* y, int64_t M, int N, int K, int act_dtype, void* stream) {
+    if (!a || !w || !pre || !y || M < 0 || N <= 0 || K <= 0 || (row_scale && rows_per_scale <= 0)) return MVIT_EINVAL;
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (M == 0) return MVIT_OK;
+    static const bool fused = getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
+    if (fused && N % G_BN == 0 && K % G_BK == 0 && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
+        return launch_linear_big_t<bf16_t, false, false, true>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
+                                                               rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
+    const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, nullptr, nullptr, 0, row_scale, rows_per_scale, y, MVIT_BF16, N, M, N, K, 0,
+                                   act_dtype, stream);
+    if (rc != MVIT_OK) return rc;
+    return mvit_gelu_bwd(pre, y, y, M * (int64_t)N, act_dtype, stream);
 }

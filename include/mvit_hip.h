@@ -131,6 +131,11 @@ int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream
  * keeps.  16-bit operands/outputs only ([M][K] a with row stride lda, [N][K] w, [M][N] pre and y). */
 int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, const float* bias, void* pre, void* y, int64_t M, int N,
                          int K, int act_dtype, void* stream);
+
+/* Backward twin: y = GELU'(pre) * row_scale[m / rows_per_scale] * (a . w^T) -- the data gradient of mlp.fc2 fused with the GELU
+ * backward (a = d_out rows, w = fc2.weight^T [N][K], pre = what mvit_linear_gelu_fwd kept); 16-bit operands / outputs. */
+int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
+                          const void* pre, void* y, int64_t M, int N, int K, int act_dtype, void* stream);
 int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
 
 /* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight) and, when db != NULL, db[n] += sum_m dy[m][n]

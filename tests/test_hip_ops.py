@@ -145,6 +145,27 @@ def test_linear_gelu_dual_output(hip_lib, M, N, K):
     _close(y, F.gelu(ref).cpu(), 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 40 + 40, 768, 192), (700, 384, 96), (2048, 1536, 384)])
+def test_linear_dgelu(hip_lib, M, N, K):
+    """fc2 data gradient fused with the GELU backward: y = GELU'(pre) * scale[row] * (a w^T) (K=96 takes the unfused route)."""
+    a = _rnd(M, K, seed=41).to(torch.bfloat16).to(DEV)
+    w = _rnd(N, K, seed=42, scale=0.08).to(torch.bfloat16).to(DEV)
+    pre = (_rnd(M, N, seed=43) * 1.5).to(torch.bfloat16).to(DEV)
+    rps = 300
+    sc = (torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(5)) * 2).to(DEV)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_linear_dgelu_fwd(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(sc), rps, _hip.ptr(pre), _hip.ptr(y), M, N, K,
+                                             _hip.BF16, _st()))
+    x = pre.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    ref = x.grad * (a.float() @ w.float().t()) * sc.repeat_interleave(rps)[:M, None]
+    _close(y, ref.cpu(), 1.5e-2)
+    y2 = torch.empty_like(y)                 # no drop-path scale
+    _hip.check(hip_lib.mvit_linear_dgelu_fwd(_hip.ptr(a), K, _hip.ptr(w), None, 0, _hip.ptr(pre), _hip.ptr(y2), M, N, K,
+                                             _hip.BF16, _st()))
+    _close(y2, (x.grad * (a.float() @ w.float().t())).cpu(), 1.5e-2)
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
