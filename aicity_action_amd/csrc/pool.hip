@@ -237,16 +237,14 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     auto prefetch = [&](int f) {
         const TA* fb = base + (int64_t)f * frame_stride;
 #pragma unroll
-        for (int i = 0; i < P::PF; ++i) {
-            pf[i] = make_uint4(0, 0, 0, 0);
-            if (poff[i] >= 0) pf[i] = *reinterpret_cast<const uint4*>(fb + poff[i]);
-        }
+        for (int i = 0; i < P::PF; ++i)       // unconditional (clamped) loads, all in flight together; padding is zeroed at commit
+            pf[i] = *reinterpret_cast<const uint4*>(fb + (poff[i] >= 0 ? poff[i] : 0));
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < P::PF; ++i) {
             const int c = tid + P::NT * i;
-            if (c < P::NCHUNK) *reinterpret_cast<uint4*>(smem + buf * P::IN_BYTES + c * 16) = pf[i];
+            if (c < P::NCHUNK) *reinterpret_cast<uint4*>(smem + buf * P::IN_BYTES + c * 16) = poff[i] >= 0 ? pf[i] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -502,26 +500,58 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
     const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
     constexpr int CW = P::CW;
 
-    auto load_in = [&](int f) {
-        for (int c = tid; c < P::NCHUNK; c += P::NT) {
+    // The next frame's input tile and d_conv tile are requested into registers BEFORE the current frame's arithmetic (unconditional
+    // loads at clamped positions, padding zeroed when they are written to LDS after it): with bounds-tested loads between two
+    // barriers every frame paid 5 dependent round trips to memory.
+    constexpr int PFI = P::PF, PFD = (P::NTOK * P::CPT + P::NT - 1) / P::NT;
+    uint4 pin[PFI], pdc[PFD];
+    int ioff[PFI], doff[PFD];          // element offsets inside one frame, -1 = padding / unused
+#pragma unroll
+    for (int i = 0; i < PFI; ++i) {
+        const int c = tid + P::NT * i;
+        ioff[i] = -1;
+        if (c < P::NCHUNK) {
             const int tok = c / P::CPT, ch = c - tok * P::CPT;
             const int iy = tok / P::IW, ix = tok - iy * P::IW;
             const int y = y_in0 + iy, x = x_in0 + ix;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (y >= 0 && y < H && x >= 0 && x < W)
-                v = *reinterpret_cast<const uint4*>(base + (((int64_t)f * H + y) * W + x) * ld + ch * CW);
-            *reinterpret_cast<uint4*>(in_lds + c * 16) = v;
+            if (y >= 0 && y < H && x >= 0 && x < W) ioff[i] = (int)((y * W + x) * ld) + ch * CW;
         }
-    };
-    auto load_dc = [&](int fo) {     // d_conv frame fo -> ring slot fo % 3 (zeros outside the image / frame range)
-        char* dst = dc_lds + (fo % 3) * DT_BYTES;
-        for (int c = tid; c < P::NTOK * P::CPT; c += P::NT) {
+    }
+#pragma unroll
+    for (int i = 0; i < PFD; ++i) {
+        const int c = tid + P::NT * i;
+        doff[i] = -1;
+        if (c < P::NTOK * P::CPT) {
             const int tok = c / P::CPT, ch = c - tok * P::CPT;
             const int yo = ty0 + tok / P::XO, xo = tx0 + tok % P::XO;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (fo >= 0 && fo < T && yo < Ho && xo < Wo)
-                v = *reinterpret_cast<const uint4*>(dbase + (((int64_t)fo * Ho + yo) * Wo + xo) * 96 + ch * CW);
-            *reinterpret_cast<uint4*>(dst + c * 16) = v;
+            if (yo < Ho && xo < Wo) doff[i] = (yo * Wo + xo) * 96 + ch * CW;
+        }
+    }
+    const int64_t in_frame = (int64_t)H * W * ld, dc_frame = (int64_t)Ho * Wo * 96;
+    auto pre_in = [&](int f) {
+        const TA* fb = base + f * in_frame;
+#pragma unroll
+        for (int i = 0; i < PFI; ++i) pin[i] = *reinterpret_cast<const uint4*>(fb + (ioff[i] >= 0 ? ioff[i] : 0));
+    };
+    auto commit_in = [&]() {
+#pragma unroll
+        for (int i = 0; i < PFI; ++i) {
+            const int c = tid + P::NT * i;
+            if (c < P::NCHUNK) *reinterpret_cast<uint4*>(in_lds + c * 16) = ioff[i] >= 0 ? pin[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto pre_dc = [&](int fo) {      // frames outside [0, T) read frame 0 and are zeroed at commit
+        const TA* fb = dbase + (fo >= 0 && fo < T ? fo : 0) * dc_frame;
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) pdc[i] = *reinterpret_cast<const uint4*>(fb + (doff[i] >= 0 ? doff[i] : 0));
+    };
+    auto commit_dc = [&](int fo) {   // d_conv frame fo -> ring slot fo % 3
+        char* dst = dc_lds + ((fo + 3) % 3) * DT_BYTES;
+        const bool fok = fo >= 0 && fo < T;
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) {
+            const int c = tid + P::NT * i;
+            if (c < P::NTOK * P::CPT) *reinterpret_cast<uint4*>(dst + c * 16) = (fok && doff[i] >= 0) ? pdc[i] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -529,11 +559,18 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t][0] = acc[t][1] = 0.f;
 
-    load_in(0);
-    load_dc(0);
-    if (T > 1) load_dc(1);
+    pre_in(0);
+    pre_dc(0);
+    commit_in();
+    commit_dc(0);
+    pre_dc(1);
+    commit_dc(1);                              // zero-filled when T == 1
     __syncthreads();
     for (int f = 0; f < T; ++f) {
+        if (f + 1 < T) {                       // next frame's tiles: in flight under this frame's arithmetic
+            pre_in(f + 1);
+            pre_dc(f + 2);
+        }
         // d_conv rows of this thread for output frames f+1, f, f-1  (tap dt = 0, 1, 2)
         float d[3][P::XO][2];
 #pragma unroll
@@ -570,8 +607,8 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
         }
         __syncthreads();                       // everyone is done with the input tile and with d_conv frame f-1
         if (f + 1 < T) {
-            load_in(f + 1);
-            load_dc(f + 2);                    // slot (f+2)%3 == (f-1)%3; zero-filled when f+2 >= T
+            commit_in();
+            commit_dc(f + 2);                  // slot (f+2)%3 == (f-1)%3; zero-filled when f+2 >= T
         }
         __syncthreads();
     }
