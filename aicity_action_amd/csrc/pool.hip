@@ -168,6 +168,9 @@ __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b)
     b = u.y;
 }
 
+#ifndef POOL_ABL
+#define POOL_ABL 0      // timing ablations (tools): 1 no conv arithmetic, 2 no LayerNorm finalize, 4 no tile loads
+#endif
 template <typename TA, int S>
 struct PoolTile {
     static constexpr int ROWS = (S == 1) ? 8 : 4;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
         const float* wm = wmine;
         asm volatile("" : "+v"(wm));   // keep the 54 weight reads inside the loop (LICM would pin 54 VGPRs)
 #pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {
+        for (int dy = 0; dy < ((POOL_ABL & 1) ? 0 : 3); ++dy) {
             float xin[P::IW][2];
             const TA* rp = tile + (S * row + dy) * P::IW * 96;
 #pragma unroll
@@ -416,10 +419,10 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
             }
         }
         // acc[0] = output frame f-1 is complete
-        if (f >= 1) finalize(f - 1);
+        if (f >= 1 && !(POOL_ABL & 2)) finalize(f - 1);
         else __syncthreads();
         if (f + 1 < T) {
-            if (!P::DB) prefetch(f + 1);   // single buffer: every thread is past its tile reads (barrier above)
+            if (!P::DB && !(POOL_ABL & 4)) prefetch(f + 1);   // single buffer: every thread is past its tile reads (barrier above)
             commit(P::DB ? ((f + 1) & 1) : 0);
         }
         __syncthreads();
