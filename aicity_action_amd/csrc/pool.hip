@@ -193,11 +193,14 @@ struct PoolTile {
 // BWD = true: the same march recomputes the conv + LayerNorm statistics and applies the LayerNorm BACKWARD in the finalize
 // step: `out` then receives d_conv (gradient wrt the conv output), `dout` is the incoming gradient, and per-block partial
 // sums of d_gamma / d_beta go to part[block][192] (accumulated in LDS with ds_add_f32).
-template <typename TA, int S, bool BWD>
+// PLAIN = true (stride 1): the bare convolution with the taps mirrored and no LayerNorm, written token-major into a slice of a
+// [B][tokens][out_ld] buffer -- the DATA gradient of the stride-1 pooling conv (input d_conv [B*heads][tokens][96] passed as
+// `qkv` with ld = 96, heads = 1; out_heads = the real head count for the output slice).
+template <typename TA, int S, bool BWD, bool PLAIN = false>
 __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     const TA* __restrict__ qkv, int64_t ld, int chan_off, const float* __restrict__ w, const float* __restrict__ gamma,
     const float* __restrict__ beta, TA* __restrict__ out, const TA* __restrict__ dout, float* __restrict__ part, int heads,
-    int T, int H, int W, int Ho, int Wo, float eps) {
+    int T, int H, int W, int Ho, int Wo, float eps, int64_t out_ld = 0, int out_chan_off = 0, int out_heads = 1) {
     using P = PoolTile<TA, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float dgam = 0.f;   // BWD: threads < 96 own one channel of the d_gamma partial (d_beta = column sum of dout, done by the caller)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     float* wl = reinterpret_cast<float*>(smem + P::NBUF * P::IN_BYTES + P::NTOK * 96 * 4);
     for (int i = tid; i < 27 * 96; i += P::NT) {
         const int tap = i / 96, c = i - tap * 96;
-        wl[i] = w[c * 27 + tap];
+        wl[i] = w[c * 27 + (PLAIN ? 26 - tap : tap)];
     }
     const float* wmine = wl + 2 * cp;
     // LayerNorm lane mapping (threads < NTOK*4): token = tid>>2, j = tid&3, 24 channels in CW-wide chunks j+4i
@@ -271,6 +274,19 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
                     const float4 t4 = *reinterpret_cast<const float4*>(stage + ltok * 96 + CW * (lj + 4 * i) + e);
                     v[i * CW + e] = t4.x; v[i * CW + e + 1] = t4.y; v[i * CW + e + 2] = t4.z; v[i * CW + e + 3] = t4.w;
                 }
+            if constexpr (PLAIN) {
+                const int yo = ty0 + ltok / P::XO, xo = tx0 + ltok % P::XO;
+                if (yo < Ho && xo < Wo) {
+                    const int ob = bh / out_heads, og = bh - ob * out_heads;
+                    TA* o = out + ((int64_t)ob * T * Ho * Wo + ((int64_t)fo * Ho + yo) * Wo + xo) * out_ld + out_chan_off + og * 96;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < CW; e += 4)
+                            store4(o + CW * (lj + 4 * i) + e, make_float4(v[i * CW + e], v[i * CW + e + 1], v[i * CW + e + 2], v[i * CW + e + 3]));
+                }
+                return;
+            }
             float sum = 0.f;
 #pragma unroll
             for (int e = 0; e < 24; ++e) sum += v[e];
@@ -647,6 +663,33 @@ static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
                        part, heads, T, H, W, Ho, Wo);
     MVIT_LAUNCH_CHECK();
     return (int)(grid.x * grid.y);
+}
+
+// internal: data gradient of the stride-1 pooling conv through the tiled kernel (PLAIN mode); dconv [B*heads][T*H*W][96] ->
+// the (chan_off) slice of dqkv [B][T*H*W][ld]
+template <typename TA>
+static int launch_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                   int H, int W, hipStream_t st) {
+    using P = PoolTile<TA, 1>;
+    dim3 grid(((W + P::XO - 1) / P::XO) * ((H + P::ROWS - 1) / P::ROWS), B * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, 1, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pool_tiled_kernel<TA, 1, false, true>), grid, dim3(P::NT), P::SMEM, st, (const TA*)dconv, (int64_t)96, 0, w,
+                       (const float*)nullptr, (const float*)nullptr, (TA*)dqkv, (const TA*)nullptr, (float*)nullptr, 1, T, H, W, H, W,
+                       0.f, ld, chan_off, heads);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+int mvit_internal_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                   int H, int W, int act_dtype, hipStream_t st) {
+    if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
+    return act_dtype == MVIT_BF16 ? launch_pool_dgrad_tiled<bf16_t>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, st)
+                                  : launch_pool_dgrad_tiled<float>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, st);
 }
 
 // internal: returns the number of [2592]-float partial rows written, or a negative error (strides 1 and 2 only)

@@ -11,6 +11,8 @@
 
 extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_scale, int64_t rows_per_scale,
                            float* out, int accumulate, float* workspace, void* stream);
+int mvit_internal_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                   int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st);
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
@@ -480,6 +482,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     if (prow < PB_MAXBLK) prow = PB_MAXBLK;
     float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes2
     const bool tiled = stride_hw == 1 || stride_hw == 2;
+    static const bool dgrad_tiled = getenv("MVIT_POOL_DGRAD_GATHER") == nullptr;
     // d_conv is complete after the first kernel; the conv weight gradient (+ its partial-row reduction) only reads it, so it is
     // issued on the library's side stream and runs beside the d_gamma / d_beta reductions and the data gradient
 #define RUN(TA)                                                                                                            \
@@ -524,9 +527,14 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         MVIT_LAUNCH_CHECK();                                                                                               \
         { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, sw); if (rr_ != MVIT_OK) return rr_; }  \
     }                                                                                                                      \
-    hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld,   \
-                       chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                    \
-    MVIT_LAUNCH_CHECK();                                                                                                   \
+    if (stride_hw == 1 && dgrad_tiled) {    /* stride 1: the data gradient IS the tiled convolution with mirrored taps */      \
+        const int dr = mvit_internal_pool_dgrad_tiled(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);      \
+        if (dr != MVIT_OK) return dr;                                                                                      \
+    } else {                                                                                                               \
+        hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld, \
+                           chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                \
+        MVIT_LAUNCH_CHECK();                                                                                               \
+    }                                                                                                                      \
     if (sw != st && !side_join(ss, st)) return MVIT_ELAUNCH;
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN
