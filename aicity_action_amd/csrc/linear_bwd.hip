@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
             for (int i = 0; i < 16; ++i) {
                 const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
                 const int kk = k0 + 96 * wq + 32 * qb + r;
+#ifdef WB_ABL
+                if (n < N && kk < K && acc[pb][qb][i] == 12345.678f) dW[(int64_t)n * K + kk] = 0.f;
+#else
                 if (n < N && kk < K) atomicAdd(dW + (int64_t)n * K + kk, acc[pb][qb][i]);
+#endif
             }
     if (do_bias && r == 0) {
 #pragma unroll
@@ -405,7 +409,12 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
             attr_done = true;
         }
         const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
-        int64_t nch = (512 + bt - 1) / bt;                      // ~2 workgroups per CU in total
+        // M chunks: every workgroup ends with a 128x192 fp32 tile of atomics (96 KiB; ~1.3 TB/s chip-wide, 25-45 % of the kernel at
+        // 512 workgroups), so fewer, longer chunks win as long as the grid stays inside ONE round of resident workgroups (512
+        // slots): 384 measured best for the 12-24-tile layers, 256 for layers with few tiles (MVIT_WGRAD_WGS overrides)
+        static const int wg_env = getenv("MVIT_WGRAD_WGS") ? atoi(getenv("MVIT_WGRAD_WGS")) : 0;
+        const int wg_target = wg_env > 0 ? wg_env : (bt <= 8 ? 256 : 384);
+        int64_t nch = (wg_target + bt - 1) / bt;
         int64_t bmc = ((M / 64 + nch - 1) / nch) * 64;          // rows per chunk, multiple of 64
         if (bmc < 512) bmc = 512;
         nch = (M + bmc - 1) / bmc;
