@@ -403,7 +403,10 @@ def _draw_train_noise(model, B, C_last, dev):
     dp_all = None
     if model.training and any(g.drop_path > 0.0 for g in model.geoms):
         # common.py:46-59 draws per DropPath call: floor(keep + U[B]) / keep
-        keep_all = torch.tensor([1.0 - g.drop_path for g in model.geoms], device=dev, dtype=torch.float32).view(-1, 1, 1)
+        keep_all = getattr(model, "_keep_all", None)       # device constant: a per-step H2D copy from pageable memory would block the
+        if keep_all is None or keep_all.device != torch.device(dev):     # host until the previous step has drained (a full sync per step)
+            keep_all = torch.tensor([1.0 - g.drop_path for g in model.geoms], device=dev, dtype=torch.float32).view(-1, 1, 1)
+            model._keep_all = keep_all
         dp_all = torch.floor(keep_all + torch.rand(len(model.geoms), 2, B, device=dev, dtype=torch.float32)) / keep_all
     mask = None
     if model.training and model.head_dropout > 0.0:

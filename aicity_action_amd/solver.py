@@ -93,6 +93,7 @@ class HipAdamW(object):
                         p.grad.zero_()
 
     def _build(self):
+        self.table_builds = getattr(self, "table_builds", 0) + 1      # each build is an H2D copy = a host sync (see step())
         rec, ptrs = [], []
         for grp in self.groups:
             for p in grp["params"]:
@@ -105,10 +106,27 @@ class HipAdamW(object):
                                 v.data_ptr() + 4 * off, min(_CHUNK, n - off), grp["weight_decay"]))
         dev = self.groups[0]["params"][0].device
         assert _hip.lib().mvit_mt_chunk_bytes() == _DT.itemsize
-        self._table = torch.from_numpy(np.array(rec, dtype=_DT).view(np.uint8).copy()).to(dev)
+        host = np.array(rec, dtype=_DT).view(np.uint8)
+        # With set_to_none the gradient addresses change every step, so this runs every step: the table goes up through a small
+        # ring of PINNED host buffers with a non-blocking copy (a copy from pageable memory blocks the host until the stream has
+        # drained -- one full sync per training step).  The kernels that read the table are ordered behind the copy on the stream.
+        ring = self.__dict__.get("_pin_ring")
+        if ring is None or ring[0][0].numel() != host.size or self._table is None or self._table.device != dev:
+            ring = [[torch.empty(host.size, dtype=torch.uint8).pin_memory(), None] for _ in range(3)]
+            self._pin_ring, self._pin_i = ring, 0
+            self._table = torch.empty(host.size, dtype=torch.uint8, device=dev)
+            self._partials = torch.empty(len(rec), dtype=torch.float32, device=dev)
+            self._out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        self._pin_i = (self._pin_i + 1) % len(ring)
+        buf, ev = ring[self._pin_i]
+        if ev is not None:
+            ev.synchronize()                                # copy issued three builds ago: long done
+        buf.numpy()[:] = host
+        self._table.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[self._pin_i][1] = ev
         self._n = len(rec)
-        self._partials = torch.empty(self._n, dtype=torch.float32, device=dev)
-        self._out2 = torch.empty(2, dtype=torch.float32, device=dev)
         self._grad_ptrs = ptrs
 
     def step(self, max_norm=None, grad_scale=None):
