@@ -168,6 +168,13 @@ __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b)
     b = u.y;
 }
 
+template <typename TA>
+__device__ __forceinline__ void store2(TA* p, float a, float b);
+template <>
+__device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b); }
+template <>
+__device__ __forceinline__ void store2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+
 #ifndef POOL_ABL
 #define POOL_ABL 0      // timing ablations (tools): 1 no conv arithmetic, 2 no LayerNorm finalize, 4 no tile loads
 #endif
@@ -663,6 +670,172 @@ static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
                        part, heads, T, H, W, Ho, Wo);
     MVIT_LAUNCH_CHECK();
     return (int)(grid.x * grid.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of the STRIDE-2 pooling conv, tiled.  dX[t][y][x] = sum over taps with (y+1-dy), (x+1-dx) even of
+// W[dt][dy][dx] * dC[t+1-dt][(y+1-dy)/2][(x+1-dx)/2]: the four parities of (y, x) are small convolutions over the d_conv grid
+// (1, 2, 2 and 4 spatial taps), so one workgroup takes a 4 x 8 block of d_conv cells (+1 halo row / column), keeps the d_conv
+// tiles of three output frames in an LDS ring and produces the 8 x 16 input tokens of every input frame from it; thread =
+// (channel pair, cell row).  Results are staged as packed 16-bit pairs and written as whole 192-byte token rows.
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+struct Dgrad2Tile {
+    static constexpr int ROWS = 4, XO = 8;
+    static constexpr int CH = ROWS + 1, CWD = XO + 1;                 // d_conv cells incl. halo
+    static constexpr int NT = 48 * ROWS;                              // 192 threads
+    static constexpr int CW = 16 / sizeof(TA), CPT = 96 / CW;
+    static constexpr int DC_CHUNKS = CH * CWD * CPT;
+    static constexpr int PF = (DC_CHUNKS + NT - 1) / NT;
+    static constexpr int DC_BYTES = CH * CWD * 96 * (int)sizeof(TA);
+    static constexpr int NTOK = 2 * ROWS * 2 * XO;                    // 128 input tokens per frame
+    static constexpr int ST_BYTES = NTOK * 96 * (int)sizeof(TA);      // staged results, act-typed
+    static constexpr int W_BYTES = 27 * 96 * 4;
+    static constexpr int SMEM = 3 * DC_BYTES + ST_BYTES + W_BYTES;
+};
+
+template <typename TA>
+__global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __restrict__ dconv, const float* __restrict__ w,
+                                                                   TA* __restrict__ dqkv, int64_t ld, int chan_off, int heads, int T,
+                                                                   int H, int W, int Ho, int Wo) {
+    using P = Dgrad2Tile<TA>;
+    constexpr int CW = P::CW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* dc_lds = smem;                                              // [3][CH*CWD][96]
+    TA* stage = reinterpret_cast<TA*>(smem + 3 * P::DC_BYTES);        // [NTOK][96]
+    float* wl = reinterpret_cast<float*>(smem + 3 * P::DC_BYTES + P::ST_BYTES);   // [tap][channel]
+    const int tid = threadIdx.x;
+    const int cp = tid % 48, row = tid / 48;
+    const int tiles_x = (Wo + P::XO - 1) / P::XO;
+    const int xo0 = (blockIdx.x % tiles_x) * P::XO, yo0 = (blockIdx.x / tiles_x) * P::ROWS;
+    const int bh = blockIdx.y;
+    const int b = bh / heads, g = bh - b * heads;
+    const TA* dbase = dconv + (int64_t)bh * T * Ho * Wo * 96;
+    for (int i = tid; i < 27 * 96; i += P::NT) {
+        const int tap = i / 96, c = i - tap * 96;
+        wl[i] = w[c * 27 + tap];
+    }
+    // register prefetch of one d_conv frame tile (unconditional clamped loads; cells outside the grid are zeroed at commit)
+    uint4 pf[P::PF];
+    int doff[P::PF];
+#pragma unroll
+    for (int i = 0; i < P::PF; ++i) {
+        const int c = tid + P::NT * i;
+        doff[i] = -1;
+        if (c < P::DC_CHUNKS) {
+            const int cell = c / P::CPT, ch = c - cell * P::CPT;
+            const int yo = yo0 + cell / P::CWD, xo = xo0 + cell % P::CWD;
+            if (yo < Ho && xo < Wo) doff[i] = (yo * Wo + xo) * 96 + ch * CW;
+        }
+    }
+    const int64_t dc_frame = (int64_t)Ho * Wo * 96;
+    auto prefetch = [&](int fo) {
+        const TA* fb = dbase + (fo >= 0 && fo < T ? fo : 0) * dc_frame;
+#pragma unroll
+        for (int i = 0; i < P::PF; ++i) pf[i] = *reinterpret_cast<const uint4*>(fb + (doff[i] >= 0 ? doff[i] : 0));
+    };
+    auto commit = [&](int fo) {     // frame fo -> ring slot (fo + 3) % 3; zeros outside [0, T) and outside the grid
+        char* dst = dc_lds + ((fo + 3) % 3) * P::DC_BYTES;
+        const bool fok = fo >= 0 && fo < T;
+#pragma unroll
+        for (int i = 0; i < P::PF; ++i) {
+            const int c = tid + P::NT * i;
+            if (c < P::DC_CHUNKS) *reinterpret_cast<uint4*>(dst + c * 16) = (fok && doff[i] >= 0) ? pf[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // input frame t needs d_conv frames t+1 (dt=0), t (dt=1), t-1 (dt=2)
+    prefetch(-1); commit(-1);
+    prefetch(0);  commit(0);
+    prefetch(1);  commit(1);
+    __syncthreads();
+    const float* wm0 = wl + 2 * cp;
+    const int64_t Nin = (int64_t)T * H * W;
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) prefetch(t + 2);          // lands under this frame's arithmetic (frame t+2 replaces t-1 after the barrier)
+        float acc[2][2 * P::XO][2];              // [input row parity][x within the 16][channel]
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int x = 0; x < 2 * P::XO; ++x) acc[py][x][0] = acc[py][x][1] = 0.f;
+        const float* wm = wm0;
+        asm volatile("" : "+v"(wm));             // keep the weight reads inside the loop
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const TA* tile = reinterpret_cast<const TA*>(dc_lds + ((t + 1 - dt + 3) % 3) * P::DC_BYTES) + 2 * cp;
+            float d0[P::CWD][2], d1[P::CWD][2];  // d_conv rows yo (= row) and yo + 1
+#pragma unroll
+            for (int x = 0; x < P::CWD; ++x) {
+                load2<TA>(tile + (row * P::CWD + x) * 96, d0[x][0], d0[x][1]);
+                load2<TA>(tile + ((row + 1) * P::CWD + x) * 96, d1[x][0], d1[x][1]);
+            }
+            // weights of this dt: wv[dy][dx]
+            float2 wv[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) wv[dy][dx] = *reinterpret_cast<const float2*>(wm + ((dt * 3 + dy) * 3 + dx) * 96);
+#pragma unroll
+            for (int xo = 0; xo < P::XO; ++xo) {
+                // even input row y = 2*yo: dy = 1 -> d_conv row yo;  odd row y = 2*yo+1: dy = 0 -> row yo+1, dy = 2 -> row yo
+                // even x = 2*xo: dx = 1 -> col xo;  odd x = 2*xo+1: dx = 0 -> col xo+1, dx = 2 -> col xo
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float w11 = c ? wv[1][1].y : wv[1][1].x, w10 = c ? wv[1][0].y : wv[1][0].x, w12 = c ? wv[1][2].y : wv[1][2].x;
+                    const float w01 = c ? wv[0][1].y : wv[0][1].x, w21 = c ? wv[2][1].y : wv[2][1].x;
+                    const float w00 = c ? wv[0][0].y : wv[0][0].x, w02 = c ? wv[0][2].y : wv[0][2].x;
+                    const float w20 = c ? wv[2][0].y : wv[2][0].x, w22 = c ? wv[2][2].y : wv[2][2].x;
+                    const float a = d0[xo][c], bq = d0[xo + 1][c], cq = d1[xo][c], dq = d1[xo + 1][c];
+                    acc[0][2 * xo][c] = fmaf(w11, a, acc[0][2 * xo][c]);
+                    acc[0][2 * xo + 1][c] = fmaf(w10, bq, fmaf(w12, a, acc[0][2 * xo + 1][c]));
+                    acc[1][2 * xo][c] = fmaf(w01, cq, fmaf(w21, a, acc[1][2 * xo][c]));
+                    acc[1][2 * xo + 1][c] = fmaf(w00, dq, fmaf(w02, cq, fmaf(w20, bq, fmaf(w22, a, acc[1][2 * xo + 1][c]))));
+                }
+            }
+        }
+        // stage the 2 x 16 tokens of this thread (channel pair cp) and write whole token rows
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int x = 0; x < 2 * P::XO; ++x) {
+                const int tok = (2 * row + py) * (2 * P::XO) + x;
+                store2<TA>(stage + tok * 96 + 2 * cp, acc[py][x][0], acc[py][x][1]);
+            }
+        __syncthreads();
+        for (int c = tid; c < P::NTOK * P::CPT; c += P::NT) {
+            const int tok = c / P::CPT, ch = c - tok * P::CPT;
+            const int y = 2 * yo0 + tok / (2 * P::XO), x = 2 * xo0 + tok % (2 * P::XO);
+            if (y < H && x < W)
+                *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * Nin + ((int64_t)t * H + y) * W + x) * ld + chan_off + g * 96 + ch * CW) =
+                    *reinterpret_cast<const uint4*>(stage + tok * 96 + ch * CW);
+        }
+        if (t + 1 < T) commit(t + 2);            // slot of frame t-1: every thread is past its reads (barrier above)
+        __syncthreads();
+    }
+}
+
+template <typename TA>
+static int launch_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                    int H, int W, int Ho, int Wo, hipStream_t st) {
+    using P = Dgrad2Tile<TA>;
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_dgrad2_tiled_kernel<TA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P::SMEM) != hipSuccess)
+            return MVIT_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pool_dgrad2_tiled_kernel<TA>), grid, dim3(P::NT), P::SMEM, st, (const TA*)dconv, w, (TA*)dqkv, ld, chan_off, heads,
+                       T, H, W, Ho, Wo);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+int mvit_internal_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                    int H, int W, int act_dtype, hipStream_t st) {
+    if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return act_dtype == MVIT_BF16 ? launch_pool_dgrad2_tiled<bf16_t>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, Ho, Wo, st)
+                                  : launch_pool_dgrad2_tiled<float>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, Ho, Wo, st);
 }
 
 // internal: data gradient of the stride-1 pooling conv through the tiled kernel (PLAIN mode); dconv [B*heads][T*H*W][96] ->

@@ -13,6 +13,8 @@ extern "C" int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const f
                            float* out, int accumulate, float* workspace, void* stream);
 int mvit_internal_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
                                    int H, int W, int act_dtype, hipStream_t st);
+int mvit_internal_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                    int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st);
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
@@ -529,6 +531,9 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     }                                                                                                                      \
     if (stride_hw == 1 && dgrad_tiled) {    /* stride 1: the data gradient IS the tiled convolution with mirrored taps */      \
         const int dr = mvit_internal_pool_dgrad_tiled(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);      \
+        if (dr != MVIT_OK) return dr;                                                                                      \
+    } else if (stride_hw == 2 && dgrad_tiled) {   /* stride 2: four parity-class convolutions over the d_conv grid, tiled */  \
+        const int dr = mvit_internal_pool_dgrad2_tiled(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);     \
         if (dr != MVIT_OK) return dr;                                                                                      \
     } else {                                                                                                               \
         hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld, \
