@@ -476,7 +476,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     if (b1 > PB_MAXBLK) b1 = PB_MAXBLK;
     int64_t b2 = (tot_in + 63) / 64;
     if (b2 > 16384) b2 = 16384;
-    int64_t b3 = (tot_out + 255) / 256;      // >= 256 tokens per block
+    int64_t b3 = (tot_out + 31) / 32;        // the per-lane token loop is a chain of dependent loads: many short blocks (<= PW_MAXBLK partial rows)
     if (b3 > PW_MAXBLK) b3 = PW_MAXBLK;
     int64_t prow = PB_MAXBLK;
     if (stride_hw == 1) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
