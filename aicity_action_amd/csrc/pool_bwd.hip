@@ -369,6 +369,82 @@ extern "C" int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H
     return (rows * 192 + wrows * 2592) * (int64_t)sizeof(float);
 }
 
+// Data gradient for strides >= 3: the 3x3 spatial footprints of neighbouring outputs do not overlap, so an input token (t, y, x)
+// receives from at most ONE spatial tap (dy = (y+1) mod s when that is < 3, output row (y+1)/s; same in x) and three temporal
+// ones; rows / columns with (y+1) mod s >= 3 get zero.  All 18 loads of a token are requested at clamped positions before the
+// arithmetic, masked by a 0/1 factor.
+template <typename TA>
+__global__ __launch_bounds__(256) void pool_dgrad_sparse_kernel(const TA* __restrict__ dconv, const float* __restrict__ w,
+                                                                TA* __restrict__ dqkv, int64_t ld, int chan_off, int B, int heads,
+                                                                int T, int H, int W, int Ho, int Wo, int s) {
+    constexpr int CW = 16 / sizeof(TA);
+    constexpr int NCH = 24 / CW;
+    __shared__ __attribute__((aligned(16))) float wsm[27 * 96];
+    for (int i = threadIdx.x; i < 27 * 96; i += 256) {
+        const int tap = i / 96, c = i - tap * 96;
+        wsm[i] = w[c * 27 + tap];
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 3;
+    const int64_t Nin = (int64_t)T * H * W;
+    const int64_t total = (int64_t)B * heads * Nin;
+    const int64_t Lout = (int64_t)T * Ho * Wo;
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < total; it0 += (int64_t)gridDim.x * 64) {
+        const int64_t it = it0 + (threadIdx.x >> 2);
+        if (it >= total) continue;
+        int64_t rem = it;
+        const int x = (int)(rem % W); rem /= W;
+        const int y = (int)(rem % H); rem /= H;
+        const int t = (int)(rem % T); rem /= T;
+        const int gh = (int)(rem % heads);
+        const int b = (int)(rem / heads);
+        const int dy = (y + 1) % s, yo = (y + 1) / s, dx = (x + 1) % s, xo = (x + 1) / s;
+        const bool sp_ok = dy < 3 && dx < 3 && yo < Ho && xo < Wo;
+        const int yc = sp_ok ? yo : 0, xc = sp_ok ? xo : 0, dyc = sp_ok ? dy : 0, dxc = sp_ok ? dx : 0;
+        const TA* pb = dconv + ((int64_t)(b * heads + gh)) * Lout * 96 + ((int64_t)yc * Wo + xc) * 96;
+        float4 v[3][NCH * CW / 4];
+        float m[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int to = t + 1 - dt;
+            const bool ok = sp_ok && to >= 0 && to < T;
+            m[dt] = ok ? 1.f : 0.f;
+            const TA* p = pb + (int64_t)(ok ? to : 0) * Ho * Wo * 96;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < CW; e += 4) v[dt][(i * CW + e) / 4] = load4(p + CW * (j + 4 * i) + e);
+        }
+        float acc[24];
+#pragma unroll
+        for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const float* wt = wsm + ((dt * 3 + dyc) * 3 + dxc) * 96;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c0 = CW * (j + 4 * i);
+#pragma unroll
+                for (int e = 0; e < CW; e += 4) {
+                    const float4 vv = v[dt][(i * CW + e) / 4];
+                    float4 ww = *reinterpret_cast<const float4*>(wt + c0 + e);
+                    ww.x *= m[dt]; ww.y *= m[dt]; ww.z *= m[dt]; ww.w *= m[dt];
+                    acc[i * CW + e] = fmaf(vv.x, ww.x, acc[i * CW + e]);
+                    acc[i * CW + e + 1] = fmaf(vv.y, ww.y, acc[i * CW + e + 1]);
+                    acc[i * CW + e + 2] = fmaf(vv.z, ww.z, acc[i * CW + e + 2]);
+                    acc[i * CW + e + 3] = fmaf(vv.w, ww.w, acc[i * CW + e + 3]);
+                }
+            }
+        }
+        TA* o = dqkv + ((int64_t)b * Nin + ((int64_t)t * H + y) * W + x) * ld + chan_off + gh * 96;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < CW; e += 4)
+                store4(o + CW * (j + 4 * i) + e, make_float4(acc[i * CW + e], acc[i * CW + e + 1], acc[i * CW + e + 2], acc[i * CW + e + 3]));
+    }
+}
+
 // LayerNorm backward of the pooling conv from what the training forward kept (xhat, rstd): one pass over rows of 96 channels,
 // 4 lanes per row.  d_conv = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-block partial sums of d_gamma = sum dy*xhat
 // and d_beta = sum dy go to part[block][192].
@@ -535,6 +611,10 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     } else if (stride_hw == 2 && dgrad_tiled) {   /* stride 2: four parity-class convolutions over the d_conv grid, tiled */  \
         const int dr = mvit_internal_pool_dgrad2_tiled(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);     \
         if (dr != MVIT_OK) return dr;                                                                                      \
+    } else if (stride_hw >= 3 && dgrad_tiled) {   /* strides >= 3: at most one spatial tap per input token */               \
+        hipLaunchKernelGGL((pool_dgrad_sparse_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, \
+                           ld, chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                            \
+        MVIT_LAUNCH_CHECK();                                                                                               \
     } else {                                                                                                               \
         hipLaunchKernelGGL((pool_dgrad_kernel<TA>), dim3((unsigned)b2), dim3(256), 0, st, (const TA*)dconv, w, (TA*)dqkv, ld, \
                            chan_off, B, heads, T, H, W, Ho, Wo, stride_hw);                                                \
