@@ -585,15 +585,22 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t][0] = acc[t][1] = 0.f;
 
-    pre_in(0);
-    pre_dc(0);
-    commit_in();
-    commit_dc(0);
-    pre_dc(1);
-    commit_dc(1);                              // zero-filled when T == 1
+    // input frames [f0, f1) of this workgroup (gridDim.z slices of T: small grids are split to fill the chip)
+    const int fz = (T + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int f0 = (int)blockIdx.z * fz, f1 = f0 + fz < T ? f0 + fz : T;
+    if (f0 < f1) {
+        pre_in(f0);
+        pre_dc(f0 - 1);
+        commit_in();
+        commit_dc(f0 - 1);                     // zero-filled outside [0, T)
+        pre_dc(f0);
+        commit_dc(f0);
+        pre_dc(f0 + 1);
+        commit_dc(f0 + 1);
+    }
     __syncthreads();
-    for (int f = 0; f < T; ++f) {
-        if (f + 1 < T) {                       // next frame's tiles: in flight under this frame's arithmetic
+    for (int f = f0; f < f1; ++f) {
+        if (f + 1 < f1) {                      // next frame's tiles: in flight under this frame's arithmetic
             pre_in(f + 1);
             pre_dc(f + 2);
         }
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
                 }
         }
         __syncthreads();                       // everyone is done with the input tile and with d_conv frame f-1
-        if (f + 1 < T) {
+        if (f + 1 < f1) {
             commit_in();
             commit_dc(f + 2);                  // slot (f+2)%3 == (f-1)%3; zero-filled when f+2 >= T
         }
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
         atomicAdd(&red[(2 * cp + 1) * 27 + t], acc[t][1]);
     }
     __syncthreads();
-    float* prow = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2592;
+    float* prow = part + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2592;
     for (int i = tid; i < 2592; i += P::NT) prow[i] = red[i];
 }
 
@@ -666,10 +673,12 @@ static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
             return MVIT_ELAUNCH;
         attr_done = true;
     }
+    // (a gridDim.z split of the frames is supported by the kernel but measured slower here: the prologue and the LDS reduction of
+    // the 2592 partial sums are paid per workgroup)
     hipLaunchKernelGGL((pool_wgrad_tiled_kernel<TA, S>), grid, dim3(P::NT), SM, st, (const TA*)qkv, ld, chan_off, (const TA*)dconv,
                        part, heads, T, H, W, Ho, Wo);
     MVIT_LAUNCH_CHECK();
-    return (int)(grid.x * grid.y);
+    return (int)(grid.x * grid.y * grid.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,14 +753,16 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
         }
     };
     // input frame t needs d_conv frames t+1 (dt=0), t (dt=1), t-1 (dt=2)
-    prefetch(-1); commit(-1);
-    prefetch(0);  commit(0);
-    prefetch(1);  commit(1);
+    const int tz = (T + (int)gridDim.z - 1) / (int)gridDim.z;     // input frames [t0, t1) of this workgroup
+    const int t0 = (int)blockIdx.z * tz, t1 = t0 + tz < T ? t0 + tz : T;
+    prefetch(t0 - 1); commit(t0 - 1);
+    prefetch(t0);     commit(t0);
+    prefetch(t0 + 1); commit(t0 + 1);
     __syncthreads();
     const float* wm0 = wl + 2 * cp;
     const int64_t Nin = (int64_t)T * H * W;
-    for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) prefetch(t + 2);          // lands under this frame's arithmetic (frame t+2 replaces t-1 after the barrier)
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) prefetch(t + 2);         // lands under this frame's arithmetic (frame t+2 replaces t-1 after the barrier)
         float acc[2][2 * P::XO][2];              // [input row parity][x within the 16][channel]
 #pragma unroll
         for (int py = 0; py < 2; ++py)
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
                 *reinterpret_cast<uint4*>(dqkv + ((int64_t)b * Nin + ((int64_t)t * H + y) * W + x) * ld + chan_off + g * 96 + ch * CW) =
                     *reinterpret_cast<const uint4*>(stage + tok * 96 + ch * CW);
         }
-        if (t + 1 < T) commit(t + 2);            // slot of frame t-1: every thread is past its reads (barrier above)
+        if (t + 1 < t1) commit(t + 2);           // slot of frame t-1: every thread is past its reads (barrier above)
         __syncthreads();
     }
 }
@@ -825,6 +836,7 @@ static int launch_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqk
             return MVIT_ELAUNCH;
         attr_done = true;
     }
+    if (grid.x * grid.y * 2 <= 512 && T >= 4) grid.z = 2;        // small grids: split the frames to fill the chip
     hipLaunchKernelGGL((pool_dgrad2_tiled_kernel<TA>), grid, dim3(P::NT), P::SMEM, st, (const TA*)dconv, w, (TA*)dqkv, ld, chan_off, heads,
                        T, H, W, Ho, Wo);
     MVIT_LAUNCH_CHECK();
