@@ -53,6 +53,8 @@ _SIGS = {
     "mvit_gelu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     "mvit_linear_gelu_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_dgelu_fwd": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    "mvit_linear_gelu_fwd_dsave": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    "mvit_linear_dact_fwd": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_wgrad": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_colsum_workspace_bytes": (c_l, [c_i]),
     "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),

@@ -257,8 +257,13 @@ class _BlockFn(torch.autograd.Function):
             w1 = hx.w(blk.mlp.fc1.weight)
             pre = torch.empty(Mq, w1.shape[0], dtype=adt, device=dev)
             hid = torch.empty_like(pre)
-            _hip.check(L.mvit_linear_gelu_fwd(_hip.ptr(vn), w1.shape[1], _hip.ptr(w1), _hip.ptr(blk.mlp.fc1.bias),
-                                              _hip.ptr(pre), _hip.ptr(hid), Mq, w1.shape[0], w1.shape[1], act, _st()), "fc1+gelu")
+            # `pre` holds GELU'(fc1 output) when both MLP GEMMs fit the 128x192 kernels (the backward then only multiplies), else the
+            # pre-activation itself
+            n1, k1 = w1.shape
+            ctx.mlp_dsave = (n1 % 192 == 0 and k1 % 64 == 0 and os.environ.get("MVIT_GELU_DSAVE", "1") != "0")
+            fc1 = L.mvit_linear_gelu_fwd_dsave if ctx.mlp_dsave else L.mvit_linear_gelu_fwd
+            _hip.check(fc1(_hip.ptr(vn), k1, _hip.ptr(w1), _hip.ptr(blk.mlp.fc1.bias), _hip.ptr(pre), _hip.ptr(hid), Mq, n1, k1, act,
+                           _st()), "fc1+gelu")
         else:
             pre = hx.linear(vn, hx.w(blk.mlp.fc1.weight), blk.mlp.fc1.bias, adt)
             hid = torch.empty_like(pre)
@@ -291,8 +296,9 @@ class _BlockFn(torch.autograd.Function):
         if act == _hip.BF16:      # fc2 data gradient and the GELU backward in one GEMM pass
             w2t = hx.wt(blk.mlp.fc2.weight)
             d_pre = torch.empty_like(pre)
-            _hip.check(L.mvit_linear_dgelu_fwd(_hip.ptr(g16), g16.shape[1], _hip.ptr(w2t), _hip.ptr(gs), grps, _hip.ptr(pre), _hip.ptr(d_pre),
-                                               Mq, w2t.shape[0], w2t.shape[1], act, _st()), "fc2 dgrad + gelu_bwd")
+            fc2d = L.mvit_linear_dact_fwd if getattr(ctx, "mlp_dsave", False) else L.mvit_linear_dgelu_fwd
+            _hip.check(fc2d(_hip.ptr(g16), g16.shape[1], _hip.ptr(w2t), _hip.ptr(gs), grps, _hip.ptr(pre), _hip.ptr(d_pre),
+                            Mq, w2t.shape[0], w2t.shape[1], act, _st()), "fc2 dgrad + gelu_bwd")
             del g16
         else:
             d_hid = hx.linear(g16, hx.wt(blk.mlp.fc2.weight), None, adt, row_scale=gs, rps=grps)

@@ -62,6 +62,20 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {      // d/dx GELU_erf
     const float erfv = x < 0.f ? -erf_abs : erf_abs;
     return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
 }
+__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gval, float& gder) {     // GELU_erf(x) and its derivative, one exp + one rcp
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    const float cdf = 0.5f * (1.0f + erfv);
+    gval = x * cdf;
+    gder = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -505,7 +519,7 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
-template <typename TO, bool RES, bool SCALE, bool DG = false>     // RES / SCALE are compile-time for the fp32 output (straight-line epilogue)
+template <typename TO, bool RES, bool SCALE, int DG = 0>     // DG: 1 = aux is the pre-activation, 2 = aux is GELU'(pre) already
 __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ residual, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
@@ -709,10 +723,15 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                     const auto t1 = __builtin_amdgcn_permlane32_swap(L.y, L.w, false, false);
                     float4& va = v[2 * qq];
                     float4& vb = v[2 * qq + 1];
-                    va.x *= gelu_grad_fast(lo16_to_f32(t0[0])); va.y *= gelu_grad_fast(hi16_to_f32(t0[0]));
-                    va.z *= gelu_grad_fast(lo16_to_f32(t1[0])); va.w *= gelu_grad_fast(hi16_to_f32(t1[0]));
-                    vb.x *= gelu_grad_fast(lo16_to_f32(t0[1])); vb.y *= gelu_grad_fast(hi16_to_f32(t0[1]));
-                    vb.z *= gelu_grad_fast(lo16_to_f32(t1[1])); vb.w *= gelu_grad_fast(hi16_to_f32(t1[1]));
+                    if constexpr (DG == 2) {
+                        va.x *= lo16_to_f32(t0[0]); va.y *= hi16_to_f32(t0[0]); va.z *= lo16_to_f32(t1[0]); va.w *= hi16_to_f32(t1[0]);
+                        vb.x *= lo16_to_f32(t0[1]); vb.y *= hi16_to_f32(t0[1]); vb.z *= lo16_to_f32(t1[1]); vb.w *= hi16_to_f32(t1[1]);
+                    } else {
+                        va.x *= gelu_grad_fast(lo16_to_f32(t0[0])); va.y *= gelu_grad_fast(hi16_to_f32(t0[0]));
+                        va.z *= gelu_grad_fast(lo16_to_f32(t1[0])); va.w *= gelu_grad_fast(hi16_to_f32(t1[0]));
+                        vb.x *= gelu_grad_fast(lo16_to_f32(t0[1])); vb.y *= gelu_grad_fast(hi16_to_f32(t0[1]));
+                        vb.z *= gelu_grad_fast(lo16_to_f32(t1[1])); vb.w *= gelu_grad_fast(hi16_to_f32(t1[1]));
+                    }
                 }
             }
             if constexpr (sizeof(TO) == 4) {
@@ -745,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     }
 }
 
-template <typename TO, bool RES, bool SCALE, bool DG = false>
+template <typename TO, bool RES, bool SCALE, int DG = 0>
 static int launch_linear_big_t(const void* a, int64_t lda, const void* w, const float* bias, const float* residual,
                                int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
                                int K, int epi, hipStream_t st) {
@@ -789,14 +808,15 @@ static int launch_linear_big(const void* a, int64_t lda, const void* w, const fl
 // tile start), which leaves the common epilogues (bias, bias+GELU) free of vector loads: the stores trail and the
 // next slab wait uses vmcnt(#stores) instead of vmcnt(0).
 // ------------------------------------------------------------------------------------------------
-// GELU: 0 = bias only, 1 = bias + GELU, 2 = both (16-bit out): y = GELU(pre) and y2 = pre, the pair a training step keeps
+// GELU: 0 = bias only, 1 = bias + GELU, 2 = both (16-bit out): y = GELU(pre) and y2 = pre, the pair a training step keeps;
+// 3 = y = GELU(pre) and y2 = GELU'(pre): the backward then only multiplies (no transcendental in its epilogue)
 template <typename TO, int GELU>   // no residual / row scale (those use linear_big_kernel)
 __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     TO* __restrict__ y2, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
     TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = (sizeof(TO) == 4 ? 24 : 12) * (GELU == 2 ? 2 : 1);     // vector stores per wave per full tile
+    constexpr int NST = (sizeof(TO) == 4 ? 24 : 12) * (GELU >= 2 ? 2 : 1);     // vector stores per wave per full tile
 
     const int ntn = N / G_BN;
     const int nt = (int)((M + G_BM - 1) / G_BM) * ntn;
@@ -949,7 +969,23 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
                         if (ok) *reinterpret_cast<uint4*>(y2 + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (qd + h)) = o;
                     }
                 }
-                if (GELU) {
+                if constexpr (GELU == 3 && sizeof(TO) == 2) {       // value and derivative from one evaluation; the derivative goes out first
+                    float4 dv[4];
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        gelu_and_grad_fast(v[qd].x, v[qd].x, dv[qd].x); gelu_and_grad_fast(v[qd].y, v[qd].y, dv[qd].y);
+                        gelu_and_grad_fast(v[qd].z, v[qd].z, dv[qd].z); gelu_and_grad_fast(v[qd].w, v[qd].w, dv[qd].w);
+                    }
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd += 2) {
+                        uint32_t a0 = pack_bf16x2(dv[qd].x, dv[qd].y), a1 = pack_bf16x2(dv[qd].z, dv[qd].w);
+                        uint32_t b0 = pack_bf16x2(dv[qd + 1].x, dv[qd + 1].y), b1 = pack_bf16x2(dv[qd + 1].z, dv[qd + 1].w);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (ok) *reinterpret_cast<uint4*>(y2 + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (qd + h)) = o;
+                    }
+                } else if (GELU) {
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         v[qd].x = gelu_fast(v[qd].x); v[qd].y = gelu_fast(v[qd].y);
@@ -1178,10 +1214,32 @@ extern "C" int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, 
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
     if (fused && N % G_BN == 0 && K % G_BK == 0 && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
-        return launch_linear_big_t<bf16_t, false, false, true>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
-                                                               rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
+        return launch_linear_big_t<bf16_t, false, false, 1>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
+                                                            rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
     const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, nullptr, nullptr, 0, row_scale, rows_per_scale, y, MVIT_BF16, N, M, N, K, 0,
                                    act_dtype, stream);
     if (rc != MVIT_OK) return rc;
     return mvit_gelu_bwd(pre, y, y, M * (int64_t)N, act_dtype, stream);
+}
+
+// The same pair with the derivative kept instead of the pre-activation: mvit_linear_gelu_fwd_dsave writes y = GELU(pre) and
+// dact = GELU'(pre) (one erf / exp evaluation for both); mvit_linear_dact_fwd multiplies the fc2 data gradient by that saved
+// factor (no transcendental in the backward epilogue).  Only for shapes of the 128x192 kernels (N % 192 == 0, K % 64 == 0): they
+// return MVIT_EUNSUPPORTED otherwise and the caller uses the pre-activation pair above.
+extern "C" int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void* w, const float* bias, void* dact, void* y, int64_t M,
+                                          int N, int K, int act_dtype, void* stream) {
+    if (!a || !w || !bias || !dact || !y || M < 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (M == 0) return MVIT_OK;
+    if (N % G_BN || K % G_BK || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    return launch_linear_pers<bf16_t, 3>(a, lda, w, bias, dact, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
+}
+extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
+                                    const void* dact, void* y, int64_t M, int N, int K, int act_dtype, void* stream) {
+    if (!a || !w || !dact || !y || M < 0 || N <= 0 || K <= 0 || (row_scale && rows_per_scale <= 0)) return MVIT_EINVAL;
+    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if (M == 0) return MVIT_OK;
+    if (N % G_BN || K % G_BK || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    return launch_linear_big_t<bf16_t, false, false, 2>(a, lda, w, nullptr, reinterpret_cast<const float*>(dact), N, row_scale,
+                                                        rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
 }

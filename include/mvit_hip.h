@@ -136,6 +136,14 @@ int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, const float*
  * backward (a = d_out rows, w = fc2.weight^T [N][K], pre = what mvit_linear_gelu_fwd kept); 16-bit operands / outputs. */
 int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
                           const void* pre, void* y, int64_t M, int N, int K, int act_dtype, void* stream);
+
+/* The same pair with the DERIVATIVE kept instead of the pre-activation: the forward writes y = GELU(pre) and dact = GELU'(pre)
+ * from one erf / exp evaluation, the backward multiplies the fc2 data gradient by dact (no transcendental in its epilogue).
+ * Shapes of the 128x192 kernels only (N % 192 == 0, K % 64 == 0), MVIT_EUNSUPPORTED otherwise. */
+int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void* w, const float* bias, void* dact, void* y, int64_t M, int N,
+                               int K, int act_dtype, void* stream);
+int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale, const void* dact,
+                         void* y, int64_t M, int N, int K, int act_dtype, void* stream);
 int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dtype, void* stream);
 
 /* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight) and, when db != NULL, db[n] += sum_m dy[m][n]

@@ -166,6 +166,36 @@ def test_linear_dgelu(hip_lib, M, N, K):
     _close(y2, (x.grad * (a.float() @ w.float().t())).cpu(), 1.5e-2)
 
 
+def test_linear_gelu_derivative_pair(hip_lib):
+    """fc1 keeps GELU'(pre) instead of pre; the fc2 data gradient multiplies by it: same result as the pre-activation pair."""
+    M, N, K = 128 * 30 + 40, 768, 192
+    a = _rnd(M, K, seed=51).to(torch.bfloat16).to(DEV)
+    w = _rnd(N, K, seed=52, scale=0.08).to(torch.bfloat16).to(DEV)
+    bias = _rnd(N, seed=53, scale=0.2).to(DEV)
+    dact = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty_like(dact)
+    _hip.check(hip_lib.mvit_linear_gelu_fwd_dsave(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(dact), _hip.ptr(y), M, N, K,
+                                                  _hip.BF16, _st()))
+    x = (a.float() @ w.float().t() + bias).requires_grad_(True)
+    g = F.gelu(x)
+    g.sum().backward()
+    _close(y, g.detach().cpu(), 1e-2)
+    _close(dact, x.grad.cpu(), 1e-2)
+    # backward side: a2 [M, K2] times w2t [N, K2] (= fc2.weight^T), scaled rows, times the saved derivative
+    K2 = 192
+    a2 = _rnd(M, K2, seed=54).to(torch.bfloat16).to(DEV)
+    w2t = _rnd(N, K2, seed=55, scale=0.08).to(torch.bfloat16).to(DEV)
+    rps = 500
+    sc = (torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(6)) * 2).to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_linear_dact_fwd(_hip.ptr(a2), K2, _hip.ptr(w2t), _hip.ptr(sc), rps, _hip.ptr(dact), _hip.ptr(out), M, N, K2,
+                                            _hip.BF16, _st()))
+    ref = dact.float() * (a2.float() @ w2t.float().t()) * sc.repeat_interleave(rps)[:M, None]
+    _close(out, ref.cpu(), 1e-2)
+    assert hip_lib.mvit_linear_gelu_fwd_dsave(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(dact), _hip.ptr(y), M, 96, K,
+                                              _hip.BF16, _st()) != 0     # N = 96: not a 128x192 shape
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
