@@ -64,8 +64,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else 0      # a launcher that narrows each rank's visibility to one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
@@ -73,9 +75,15 @@ def main():
     cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision, "HIP.STREAMS", args.streams])
     mv = copy.deepcopy(cfg.MVIT.to_dict())
     train = args.mode == "train"
+    manual_ddp = False
     if train and world > 1:
-        cfg.NUM_GPUS = world              # build_model wraps DistributedDataParallel (slowfast/models/build.py:47-54)
-    model = build_model(cfg, gpu_id=local_rank)
+        if world <= ndev:
+            cfg.NUM_GPUS = world          # build_model wraps DistributedDataParallel (slowfast/models/build.py:47-54)
+        else:
+            manual_ddp = True             # fewer visible devices than ranks: same wrap, applied here
+    model = build_model(cfg, gpu_id=dev_index)
+    if manual_ddp:
+        model = torch.nn.parallel.DistributedDataParallel(module=model, device_ids=[dev_index], output_device=dev_index)
     core = model.module if hasattr(model, "module") else model
     load_synth_weights(core, 0)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
