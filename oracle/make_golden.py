@@ -29,6 +29,7 @@ from aicity_action_amd.utils.synth import load_synth_weights, synth_clip  # noqa
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 MAX_SAMPLE = 2048
+FULL_TRAIN_SAMPLE = 768     # per-parameter gradient / post-step samples of the full-size train fixtures (350 tensors each)
 
 TINY = {
     "MVIT.DEPTH": 4,
@@ -49,11 +50,92 @@ CASES = {
 }
 
 
-def sample(t):
-    """Strided sample of a tensor (<= MAX_SAMPLE elements) + first two moments."""
+def sample(t, cap=MAX_SAMPLE):
+    """Strided sample of a tensor (<= cap elements) + first two moments."""
     f = t.detach().reshape(-1).to(torch.float32)
-    stride = max(1, (f.numel() + MAX_SAMPLE - 1) // MAX_SAMPLE)
+    stride = max(1, (f.numel() + cap - 1) // cap)
     return f[::stride].numpy().copy(), np.array([f.mean().item(), f.abs().mean().item(), stride, f.numel()], np.float64)
+
+
+def train_golden(name, yaml_name, ov, batch, clip, sd, out, meta, cap):
+    """One train step of the REAL reference (tools/train_net.py:201-246 order: forward, loss, zero_grad, backward,
+    clip_grad_norm_, AdamW step) with drop-path / dropout off, checked against autograd over the restatement, then
+    written as: loss, train-mode logits, global gradient norm, per-parameter post-clip gradient samples + moments
+    (+ each tensor's own L2 norm) and post-step parameter samples."""
+    ov2 = dict(ov, **{"MVIT.DROPPATH_RATE": 0.0, "MODEL.DROPOUT_RATE": 0.0})
+    cfg2 = reference_cfg(yaml_name, ov2)
+    mv2 = mvit_dict(cfg2)
+    m2 = build_reference_model(cfg2).train()
+    load_synth_weights(m2, 0)
+    labels = torch.zeros(batch, cfg2.MODEL.NUM_CLASSES)
+    for b in range(batch):
+        labels[b, (3 * b + 1) % cfg2.MODEL.NUM_CLASSES] = 0.9
+        labels[b, (5 * b + 2) % cfg2.MODEL.NUM_CLASSES] = 0.1
+    from slowfast.models import optimizer as ref_optim
+    from slowfast.models.losses import get_loss_func
+    from slowfast.utils.lr_policy import get_lr_at_epoch
+    opt = ref_optim.construct_optimizer(m2, cfg2)
+    cur_epoch = 0.25
+    lr = get_lr_at_epoch(cfg2, cur_epoch)
+    ref_optim.set_lr(opt, lr)
+    preds = m2([clip])
+    loss = get_loss_func(cfg2.MODEL.LOSS_FUNC)(reduction="mean")(preds, labels)
+    opt.zero_grad()
+    loss.backward()
+    ref_tot64 = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m2.parameters())).item()   # pre-clip, fp64 accumulation
+    gnorm = torch.nn.utils.clip_grad_norm_(m2.parameters(), cfg2.SOLVER.CLIP_GRAD_L2NORM)
+    grads = {k: p.grad.detach().clone() for k, p in m2.named_parameters()}  # post-clip (in place)
+    opt.step()
+    preds = preds.detach()
+    loss_v = loss.item()
+    del loss
+    # oracle side
+    sd2 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    o_out, o_lg = O.forward(sd2, clip, mv2, training=True)
+    o_loss = O.soft_target_cross_entropy(o_out, labels)
+    o_loss.backward()
+    assert abs(o_loss.item() - loss_v) <= 1e-6, (o_loss.item(), loss_v)
+    assert abs(O.lr_at_epoch({k: cfg2.SOLVER[k] for k in cfg2.SOLVER}, cur_epoch) - lr) < 1e-12
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd2.values())).item()
+    # the restatement's norm against the reference's, both accumulated in fp64; clip_grad_norm_ itself accumulates 35 M squares
+    # in fp32 (2e-5 off at the full sizes), so its own value is only held to 1e-4 and the clip coefficient is taken from it
+    assert abs(tot - ref_tot64) <= 1e-5 * max(1.0, tot), (tot, ref_tot64)
+    assert abs(tot - gnorm.item()) <= 1e-4 * max(1.0, tot), (tot, gnorm.item())
+    coef = min(1.0, cfg2.SOLVER.CLIP_GRAD_L2NORM / (gnorm.item() + 1e-6))
+    for k in grads:
+        d = (sd2[k].grad * coef - grads[k]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, grads[k].abs().max().item()) + 1e-7, (k, d)
+    print("[%s] oracle grads==reference grads (loss %.6f, |g| %.4f, lr %.3e)" % (name, loss_v, tot, lr))
+    out["train.labels"] = labels.numpy()
+    out["train.loss"] = np.array(loss_v, np.float64)
+    out["train.logits"] = preds.numpy()
+    out["train.grad_norm"] = np.array(gnorm.item(), np.float64)
+    if cap != MAX_SAMPLE:
+        out["train.grad_norm_fp64"] = np.array(ref_tot64, np.float64)
+    out["train.lr"] = np.array(lr, np.float64)
+    groups = [[], []]
+    name_of = {id(p): k for k, p in m2.named_parameters()}
+    for gi, g in enumerate(opt.param_groups):
+        for p in g["params"]:
+            groups[0 if g["weight_decay"] > 0 else 1].append(name_of[id(p)])
+    meta["wd_group"] = groups[0]
+    meta["no_wd_group"] = groups[1]
+    meta["train_overrides"] = ov2
+    meta["weight_decay"] = cfg2.SOLVER.WEIGHT_DECAY
+    meta["clip"] = cfg2.SOLVER.CLIP_GRAD_L2NORM
+    meta["solver"] = {k: cfg2.SOLVER[k] for k in cfg2.SOLVER}
+    new_sd = m2.state_dict()
+    l2 = {}
+    for k in grads:
+        s, mom = sample(grads[k], cap)
+        out["grad." + k] = s
+        out["gmom." + k] = mom
+        l2[k] = float(grads[k].double().norm().item())
+        s, mom = sample(new_sd[k], cap)
+        out["step." + k] = s
+    if cap != MAX_SAMPLE:           # full-size fixtures: per-tensor gradient L2 norms (post-clip) for the per-parameter checks
+        out["train.grad_l2"] = np.array([l2[k] for k in grads], np.float64)
+        meta["grad_keys"] = list(grads.keys())
 
 
 def mvit_dict(cfg):
@@ -111,68 +193,18 @@ def run_case(name):
             "n_params": int(sum(p.numel() for p in model.parameters())),
             "state_keys": list(sd.keys()), "state_shapes": [list(v.shape) for v in sd.values()]}
 
-    # --- train step (tiny cases only): loss, grads, one clipped AdamW step -----------------
+    # --- train step: loss, grads, one clipped AdamW step -----------------------------------
+    # tiny cases: inside the case's own fixture; full-size cases (BASELINE configs[0] / configs[2] geometry, B=1): a
+    # separate mvit_<name>_train.npz (fewer samples per tensor) so the forward fixtures stay byte-identical
     if name.startswith("tiny"):
-        ov2 = dict(ov, **{"MVIT.DROPPATH_RATE": 0.0, "MODEL.DROPOUT_RATE": 0.0})
-        cfg2 = reference_cfg(yaml_name, ov2)
-        mv2 = mvit_dict(cfg2)
-        m2 = build_reference_model(cfg2).train()
-        load_synth_weights(m2, 0)
-        labels = torch.zeros(batch, cfg2.MODEL.NUM_CLASSES)
-        for b in range(batch):
-            labels[b, (3 * b + 1) % cfg2.MODEL.NUM_CLASSES] = 0.9
-            labels[b, (5 * b + 2) % cfg2.MODEL.NUM_CLASSES] = 0.1
-        from slowfast.models import optimizer as ref_optim
-        from slowfast.models.losses import get_loss_func
-        from slowfast.utils.lr_policy import get_lr_at_epoch
-        opt = ref_optim.construct_optimizer(m2, cfg2)
-        cur_epoch = 0.25
-        lr = get_lr_at_epoch(cfg2, cur_epoch)
-        ref_optim.set_lr(opt, lr)
-        preds = m2([clip])
-        loss = get_loss_func(cfg2.MODEL.LOSS_FUNC)(reduction="mean")(preds, labels)
-        opt.zero_grad()
-        loss.backward()
-        gnorm = torch.nn.utils.clip_grad_norm_(m2.parameters(), cfg2.SOLVER.CLIP_GRAD_L2NORM)
-        grads = {k: p.grad.detach().clone() for k, p in m2.named_parameters()}  # post-clip (in place)
-        opt.step()
-        # oracle side
-        sd2 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-        o_out, o_lg = O.forward(sd2, clip, mv2, training=True)
-        o_loss = O.soft_target_cross_entropy(o_out, labels)
-        o_loss.backward()
-        assert abs(o_loss.item() - loss.item()) <= 1e-6, (o_loss.item(), loss.item())
-        assert abs(O.lr_at_epoch({k: cfg2.SOLVER[k] for k in cfg2.SOLVER}, cur_epoch) - lr) < 1e-12
-        tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd2.values())).item()
-        assert abs(tot - gnorm.item()) <= 1e-5 * max(1.0, tot), (tot, gnorm.item())
-        coef = min(1.0, cfg2.SOLVER.CLIP_GRAD_L2NORM / (tot + 1e-6))
-        for k in grads:
-            d = (sd2[k].grad * coef - grads[k]).abs().max().item()
-            assert d <= 1e-5 * max(1.0, grads[k].abs().max().item()) + 1e-7, (k, d)
-        print("[%s] oracle grads==reference grads (loss %.6f, |g| %.4f, lr %.3e)" % (name, loss.item(), tot, lr))
-        out["train.labels"] = labels.numpy()
-        out["train.loss"] = np.array(loss.item(), np.float64)
-        out["train.logits"] = preds.detach().numpy()
-        out["train.grad_norm"] = np.array(gnorm.item(), np.float64)
-        out["train.lr"] = np.array(lr, np.float64)
-        groups = [[], []]
-        name_of = {id(p): k for k, p in m2.named_parameters()}
-        for gi, g in enumerate(opt.param_groups):
-            for p in g["params"]:
-                groups[0 if g["weight_decay"] > 0 else 1].append(name_of[id(p)])
-        meta["wd_group"] = groups[0]
-        meta["no_wd_group"] = groups[1]
-        meta["train_overrides"] = ov2
-        meta["weight_decay"] = cfg2.SOLVER.WEIGHT_DECAY
-        meta["clip"] = cfg2.SOLVER.CLIP_GRAD_L2NORM
-        meta["solver"] = {k: cfg2.SOLVER[k] for k in cfg2.SOLVER}
-        new_sd = m2.state_dict()
-        for k in grads:
-            s, mom = sample(grads[k])
-            out["grad." + k] = s
-            out["gmom." + k] = mom
-            s, mom = sample(new_sd[k])
-            out["step." + k] = s
+        train_golden(name, yaml_name, ov, batch, clip, sd, out, meta, MAX_SAMPLE)
+    elif os.environ.get("GOLDEN_SKIP_FULL_TRAIN", "0") != "1":
+        tout, tmeta = {}, dict(meta)
+        train_golden(name, yaml_name, ov, batch, clip, sd, tout, tmeta, FULL_TRAIN_SAMPLE)
+        tout["meta"] = np.frombuffer(json.dumps(tmeta).encode(), dtype=np.uint8)
+        tpath = os.path.join(GOLD, "mvit_%s_train.npz" % name)
+        np.savez_compressed(tpath, **tout)
+        print("wrote", tpath, "%.1f KB" % (os.path.getsize(tpath) / 1024))
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(GOLD, "mvit_%s.npz" % name)
     np.savez_compressed(path, **out)

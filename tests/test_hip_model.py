@@ -20,7 +20,7 @@ from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
 pytestmark = pytest.mark.gpu
 
 FP32_LOGIT_TOL = 1e-4
-BF16_LOGIT_TOL = 1e-2
+BF16_LOGIT_TOL = 6e-3          # observed 1.7e-3 (tiny) / 3.6e-3 (@224) / 5.1e-3 (@448); the 1e-3 gate is met by fp32 and fp16
 BF16_PROB_TOL = 1e-3
 
 

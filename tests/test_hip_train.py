@@ -96,59 +96,119 @@ def test_drop_path_and_dropout_statistics():
     assert torch.equal(c, d) and torch.allclose(c.sum(1), torch.ones(2, device=c.device), atol=1e-5)
 
 
-@pytest.mark.parametrize("crop", [224, 448])
-def test_full_size_backward_against_oracle_autograd(crop):
-    """BASELINE configs (MViTv2-B 16x4, all 16 blocks, real sizes; @224 = configs[0], @448 = the measured one), one clip: the
-    hand-written bf16 backward against torch autograd over the CPU oracle (fp32), drop-path / dropout off.  Checks the loss, the
-    global gradient norm, the cosine of the full gradient vector and every parameter's own gradient direction -- the training
-    path at the size bench.py measures.  Each case costs 5-6 minutes of host time for the oracle's autograd, so they only run with
-    MVIT_SLOW_TESTS=1; the last recorded results are in profiles/r1_full_size_backward_parity.txt (@448: cosine 0.999973, |g|
-    within 0.03 %, worst parameter cosine 0.9992; @224: cosine 0.999944, worst 0.9988)."""
-    import copy
+def _full_train_step(name, precision):
+    """One train step (forward, soft-target CE, backward, fused clip + AdamW) at a BASELINE geometry, drop-path / dropout off,
+    as recorded in tests/golden/mvit_<name>_train.npz by the REAL reference (oracle/make_golden.py:train_golden)."""
+    z, meta, cfg, model, clip, labels = _setup(name + "_train", precision)
+    opt = construct_optimizer(model, cfg)
+    lr = get_lr_at_epoch(cfg, 0.25)
+    assert abs(lr - float(z["train.lr"])) < 1e-12
+    opt.set_lr(lr)
+    logits = model([clip])
+    loss = soft_target_cross_entropy(logits, labels)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    out2 = opt.step()
+    torch.cuda.synchronize()
+    return z, meta, model, logits.detach(), loss.item(), grads, out2[0].item(), out2[1].item()
+
+
+@pytest.mark.parametrize("name", ["full224", "full448"])
+def test_full_size_fp32_train_step_matches_reference_golden(name):
+    """BASELINE configs[0] / configs[2] geometry (16 blocks, real token counts), B=1, exact-fp32 kernels: loss 1e-5, gradient
+    norm, every parameter's gradient samples <= 1e-4 relative, parameters after the clipped AdamW step."""
+    z, meta, model, logits, loss, grads, tot, coef = _full_train_step(name, "fp32")
+    assert np.abs(logits.cpu().numpy() - z["train.logits"]).max() <= 1e-4
+    assert abs(loss - float(z["train.loss"])) <= 1e-5
+    assert abs(tot - float(z["train.grad_norm_fp64"])) <= 1e-4 * tot
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gref = z["grad." + k]
+        got = sample_like(grads[k] * coef, z["gmom." + k])
+        err = np.abs(got - gref).max() / max(1.0, np.abs(gref).max())
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, err)
+        assert np.abs(sample_like(p, z["gmom." + k]) - z["step." + k]).max() <= 5e-6, k
+    print("[%s fp32 train] loss %.6f |g| %.4f worst relative gradient error %.2e" % (name, loss, tot, worst))
+
+
+@pytest.mark.parametrize("name", ["full224", "full448"])
+def test_full_size_bf16_train_step_vs_reference_golden(name):
+    """The benchmarked precision at the benchmarked geometry (configs[2] @448): the bf16 MFMA forward + hand-written backward
+    against the reference's fp32 train step.  Bounds: loss 2e-2, global |g| within 3 %, cosine of the sampled gradient vector
+    >= 0.998, every parameter tensor's own |g| within 10 % (tensors whose gradient is above the noise floor), and the
+    sign of the gradient (= the direction of the first Adam update) agreeing on >= 97 % of the sampled elements whose reference
+    gradient is not tiny."""
+    z, meta, model, logits, loss, grads, tot, coef = _full_train_step(name, "bf16")
+    ref_tot = float(z["train.grad_norm_fp64"])
+    assert np.abs(logits.cpu().numpy() - z["train.logits"]).max() <= 2e-2
+    assert abs(loss - float(z["train.loss"])) <= 2e-2
+    assert abs(tot - ref_tot) <= 0.03 * ref_tot
+    a, b = [], []
+    worst_l2, worst_name = 0.0, ""
+    ref_coef = min(1.0, meta["clip"] / (float(z["train.grad_norm"]) + 1e-6))
+    for k, p in model.named_parameters():
+        assert k in meta["grad_keys"]
+        a.append(sample_like(grads[k] * coef, z["gmom." + k]))
+        b.append(z["grad." + k])
+        mine = float(grads[k].double().norm()) * coef
+        ref_l2 = float(z["train.grad_l2"][meta["grad_keys"].index(k)])
+        if ref_l2 > 1e-4 * ref_tot * ref_coef:
+            rel = abs(mine - ref_l2) / ref_l2
+            if rel > worst_l2:
+                worst_l2, worst_name = rel, k
+    a, b = np.concatenate(a), np.concatenate(b)
+    cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+    big = np.abs(b) > 0.05 * np.abs(b).mean()
+    agree = float((np.sign(a[big]) == np.sign(b[big])).mean())
+    print("[%s bf16 train] loss %.5f (ref %.5f) |g| %.4f (ref %.4f) cosine %.6f worst per-tensor |g| deviation %.3f (%s) sign agreement %.4f"
+          % (name, loss, float(z["train.loss"]), tot, ref_tot, cos, worst_l2, worst_name, agree))
+    assert cos >= 0.998
+    assert worst_l2 <= 0.10, (worst_name, worst_l2)
+    assert agree >= 0.97
+
+
+def test_bench_size_bf16_train_step_properties():
+    """BASELINE configs[2] exactly as bench.py runs it (B=8 @448 bf16, drop-path / dropout off here so the step is a
+    function of its inputs): finite everywhere; the batch loss is the mean of the eight B=1 losses of the same clips
+    (same kernels, so the tolerance is only the different reduction order); every clip's logits equal its B=1 logits; two
+    identical steps agree run to run to the weight-gradient reduction order (bit-identical once the reduction is ordered)."""
     import os
-    import sys
-    if os.environ.get("MVIT_SLOW_TESTS", "0") != "1":
-        pytest.skip("5-6 minutes of oracle autograd on the host per case: set MVIT_SLOW_TESTS=1 (results: profiles/r1_full_size_backward_parity.txt)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "oracle"))
-    import mvit_oracle as O
-    from aicity_action_amd.autograd import forward_train
+    from conftest import ROOT
     from aicity_action_amd.config import load_config
-    yaml = "MVITV2_FULL_B_16x4_CONV_448.yaml" if crop == 448 else "MVITV2_FULL_B_16x4_CONV.yaml"
-    cfg = load_config(os.path.join(root, "configs", "Aicity", yaml),
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV_448.yaml"),
                       ["NUM_GPUS", 1, "HIP.PRECISION", "bf16", "MVIT.DROPPATH_RATE", 0.0, "MODEL.DROPOUT_RATE", 0.0])
-    mv = copy.deepcopy(cfg.MVIT.to_dict())
     model = build_model(cfg).train()
     load_synth_weights(model, 0)
-    model.head_dropout = 0.0
-    for g in model.geoms:
-        g.drop_path = 0.0
-    clip = synth_clip(1, 16, crop, 11)
-    w = torch.linspace(-1.0, 1.0, 18).reshape(1, 18)
-    lg = forward_train(model, clip.cuda())
-    loss = (lg * w.cuda()).sum()
-    loss.backward()
-    torch.cuda.synchronize()
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    torch.set_num_threads(os.cpu_count() or 8)
-    _, o_lg = O.forward(sdg, clip, mv, training=False, head_act=False)
-    o_loss = (o_lg * w).sum()
-    o_loss.backward()
-    assert (lg.detach().cpu() - o_lg.detach()).abs().max().item() <= 2e-2       # bf16 path: reference's own bf16 deviation is ~4e-3
-    dot = na = nb = 0.0
-    worst_cos, worst_name = 1.0, ""
-    for k, p in model.named_parameters():
-        a, b = p.grad.detach().double().cpu().flatten(), sdg[k].grad.double().flatten()
-        d, x, y = float(a @ b), float(a @ a), float(b @ b)
-        dot, na, nb = dot + d, na + x, nb + y
-        if y > 1e-16 * max(1.0, float(b.numel())):          # parameters with an (analytically) zero gradient carry only noise
-            c = d / max(1e-30, (x * y) ** 0.5)
-            if c < worst_cos:
-                worst_cos, worst_name = c, k
-    cos = dot / (na * nb) ** 0.5
-    print("[full%d bf16 backward] loss %.5f (oracle %.5f)  |g| %.5f (oracle %.5f)  cosine %.6f  worst parameter %s %.4f" % (
-        crop, loss.item(), o_loss.item(), na ** 0.5, nb ** 0.5, cos, worst_name, worst_cos))
-    assert abs(na ** 0.5 - nb ** 0.5) <= 0.03 * nb ** 0.5
-    assert cos >= 0.998
-    assert worst_cos >= 0.95, (worst_name, worst_cos)
+    B = 8
+    clip = synth_clip(B, 16, 448, 21).cuda()
+    labels = torch.zeros(B, 18, device="cuda")
+    labels[torch.arange(B), torch.arange(B) % 18] = 1.0
+
+    def run(c, y):
+        for p in model.parameters():
+            p.grad = None
+        lg = model([c])
+        ls = soft_target_cross_entropy(lg, y)
+        ls.backward()
+        return lg.detach().clone(), ls.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    lg8, loss8, g8 = run(clip, labels)
+    assert np.isfinite(loss8) and torch.isfinite(lg8).all()
+    for k, g in g8.items():
+        assert torch.isfinite(g).all(), k
+    singles, gsum = [], None
+    for i in range(B):
+        lg1, l1, g1 = run(clip[i:i + 1], labels[i:i + 1])
+        assert (lg1[0] - lg8[i]).abs().max().item() <= 1e-6 * max(1.0, lg8.abs().max().item())   # per-clip arithmetic is batch-independent
+        singles.append(l1)
+        gsum = g1 if gsum is None else {k: gsum[k] + g1[k] for k in g1}
+    assert abs(loss8 - float(np.mean(singles))) <= 1e-5
+    num = sum(float(((g8[k].double() - gsum[k].double() / B) ** 2).sum()) for k in g8)
+    den = sum(float((g8[k].double() ** 2).sum()) for k in g8)
+    print("[B=8 @448 bf16] loss %.5f; |g8 - mean(g1)| / |g8| = %.2e" % (loss8, (num / den) ** 0.5))
+    assert (num / den) ** 0.5 <= 2e-3      # same products; only the 16-bit roundings of batch-summed intermediates differ
+    lg8b, loss8b, g8b = run(clip, labels)
+    assert torch.equal(lg8, lg8b) and loss8 == loss8b
+    num = sum(float(((g8[k].double() - g8b[k].double()) ** 2).sum()) for k in g8)
+    print("[B=8 @448 bf16] run-to-run gradient difference %.2e (relative)" % ((num / den) ** 0.5))
+    assert (num / den) ** 0.5 <= 1e-5

@@ -70,3 +70,29 @@ def test_oracle_train_step_matches_reference_golden(name):
         p = p - lr * (m / 0.1) / ((s / 0.001).sqrt() + 1e-8)
         got = sample_like(p, z["gmom." + k])
         assert np.abs(got - z["step." + k]).max() <= 2e-6, k
+
+
+def test_oracle_full224_train_step_matches_reference_golden():
+    """BASELINE configs[0] geometry (all 16 blocks, real widths), one clip: loss, train-mode logits, gradient norm and every
+    parameter's post-clip gradient samples of the REAL reference's train step (tests/golden/mvit_full224_train.npz) against
+    autograd over the restatement.  (@448 the same check needs ~20 GB / 1 min of host autograd: oracle/make_golden.py runs it
+    when the fixture is generated.)"""
+    z, meta = load_golden("full224_train")
+    cfg = cfg_for_case(meta, train=True)
+    sd = synth_state_dict(dict(zip(meta["state_keys"], meta["state_shapes"])), meta["weight_seed"])
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"])
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    out, _ = O.forward(sd, clip, _mv(cfg), training=True)
+    loss = O.soft_target_cross_entropy(out, torch.from_numpy(z["train.labels"]))
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) <= 1e-6
+    assert np.abs(out.detach().numpy() - z["train.logits"]).max() <= 1e-5
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values())).item()
+    assert abs(tot - float(z["train.grad_norm_fp64"])) <= 1e-5 * tot
+    coef = min(1.0, meta["clip"] / (float(z["train.grad_norm"]) + 1e-6))     # the reference's own (fp32-accumulated) norm
+    for k, l2 in zip(meta["grad_keys"], z["train.grad_l2"]):
+        g = sd[k].grad * coef
+        got = sample_like(g, z["gmom." + k])
+        gref = z["grad." + k]
+        assert np.abs(got - gref).max() <= 1e-5 * max(1.0, np.abs(gref).max()) + 1e-7, k
+        assert abs(float(g.double().norm()) - l2) <= 1e-5 * max(l2, 1e-3), k
