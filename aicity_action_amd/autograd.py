@@ -202,8 +202,29 @@ class _StemFn(torch.autograd.Function):
 
 
 class _BlockFn(torch.autograd.Function):
+    """One MultiScaleBlock.  With ``hx.m.use_act_checkpoint`` (MODEL.ACT_CHECKPOINT, video_model_builder.py:1036-1037: the
+    reference wraps every block in fairscale's checkpoint_wrapper) only the block input and the two drop-path draws are kept:
+    the forward kernels run a second time at the start of ``backward`` to rebuild the activations, exactly the memory / time
+    trade of the reference's recipe (README.md:84,96-114).  ``_BlockFn.forward_launches`` counts forward executions (tests)."""
+    forward_launches = 0
+
     @staticmethod
     def forward(ctx, x, hx, g, blk, dp1, dp2, *params):
+        out, saved, pool_saved, mlp_dsave = _BlockFn._run_forward(x, hx, g, blk, dp1, dp2)
+        ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, 1 if hx.m.use_query_residual_pool else 0
+        ctx.mlp_dsave = mlp_dsave
+        if hx.m.use_act_checkpoint:
+            ctx.saved, ctx.pool_saved = None, None
+            ctx.recompute = (x, dp1, dp2)
+        else:
+            ctx.saved, ctx.pool_saved = saved, pool_saved
+            ctx.recompute = None
+        return out
+
+    @staticmethod
+    def _run_forward(x, hx, g, blk, dp1, dp2):
+        _BlockFn.forward_launches += 1
+        mlp_dsave = False
         L, act, adt = hx.L, hx.act, hx.adt
         dev = x.device
         at = blk.attn
@@ -260,8 +281,8 @@ class _BlockFn(torch.autograd.Function):
             # `pre` holds GELU'(fc1 output) when both MLP GEMMs fit the 128x192 kernels (the backward then only multiplies), else the
             # pre-activation itself
             n1, k1 = w1.shape
-            ctx.mlp_dsave = (n1 % 192 == 0 and k1 % 64 == 0 and os.environ.get("MVIT_GELU_DSAVE", "1") != "0")
-            fc1 = L.mvit_linear_gelu_fwd_dsave if ctx.mlp_dsave else L.mvit_linear_gelu_fwd
+            mlp_dsave = (n1 % 192 == 0 and k1 % 64 == 0 and os.environ.get("MVIT_GELU_DSAVE", "1") != "0")
+            fc1 = L.mvit_linear_gelu_fwd_dsave if mlp_dsave else L.mvit_linear_gelu_fwd
             _hip.check(fc1(_hip.ptr(vn), k1, _hip.ptr(w1), _hip.ptr(blk.mlp.fc1.bias), _hip.ptr(pre), _hip.ptr(hid), Mq, n1, k1, act,
                            _st()), "fc1+gelu")
         else:
@@ -269,18 +290,23 @@ class _BlockFn(torch.autograd.Function):
             hid = torch.empty_like(pre)
             _hip.check(L.mvit_gelu_fwd(_hip.ptr(pre), _hip.ptr(hid), pre.numel(), act, _st()), "gelu")
         out = hx.linear(hid, hx.w(blk.mlp.fc2.weight), blk.mlp.fc2.bias, torch.float32, residual=y, row_scale=dp2, rps=Lq)
-        ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, addq
-        ctx.saved = (x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2)
-        ctx.pool_saved = pool_saved
-        return out.view(B, Lq, Cout)
+        saved = (x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2)
+        return out.view(B, Lq, Cout), saved, pool_saved, mlp_dsave
 
     @staticmethod
     def backward(ctx, d_out):
         hx, g, blk = ctx.hx, ctx.g, ctx.blk
         L, act, adt = hx.L, hx.act, hx.adt
-        x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2 = ctx.saved
+        if ctx.recompute is not None:          # activation checkpointing: rebuild the block's activations from its input
+            xin, rdp1, rdp2 = ctx.recompute
+            ctx.recompute = None
+            _, saved, pool_saved, _ = _BlockFn._run_forward(xin, hx, g, blk, rdp1, rdp2)
+            del xin
+        else:
+            saved, pool_saved = ctx.saved, ctx.pool_saved
+        x2, u, qkv, q, k, v, o, lse, r_full, y, vn, pre, hid, dp1, dp2 = saved
+        del saved
         ctx.saved = None
-        pool_saved = ctx.pool_saved
         ctx.pool_saved = None
         at = blk.attn
         dev = x2.device
@@ -428,14 +454,8 @@ def _forward_train_one(model, clip, hx, dp_all, mask):
         dp1 = dp2 = None
         if dp_all is not None and g.drop_path > 0.0:
             dp1, dp2 = dp_all[i, 0].contiguous(), dp_all[i, 1].contiguous()
-        if model.use_act_checkpoint and torch.is_grad_enabled():
-            # MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037, attention.py checkpoint.checkpoint(blk, x, thw)): keep only
-            # the block input, run the block's forward again inside backward.  The drop-path draws are made outside.
-            from torch.utils.checkpoint import checkpoint
-            x = checkpoint(lambda xx, g=g, blk=blk, dp1=dp1, dp2=dp2: _BlockFn.apply(xx, hx, g, blk, dp1, dp2, *_block_params(blk, g)),
-                           x, use_reentrant=False)
-        else:
-            x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
+        # MODEL.ACT_CHECKPOINT is handled inside _BlockFn (input + drop-path draws kept, forward re-run in backward)
+        x = _BlockFn.apply(x, hx, g, blk, dp1, dp2, *_block_params(blk, g))
     hp = model.head.projection
     return _HeadFn.apply(x, model.norm.weight, model.norm.bias, hp.weight, hp.bias, mask, hx)
 

@@ -556,6 +556,10 @@ __global__ __launch_bounds__(256) void adamw_chunks_kernel(const MtChunk* __rest
                                                            float bc2_sqrt) {
     const MtChunk c = ch[blockIdx.x];
     const float coef = coef_ptr ? coef_ptr[1] : 1.0f;
+    // a non-finite global norm (NaN / inf loss or gradient) must not reach the parameters or the moments: skip the whole step
+    // (bit test: the build uses -fno-honor-nans)
+    if (coef_ptr && (((__float_as_uint(coef_ptr[0]) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(coef) & 0x7f800000u) == 0x7f800000u)))
+        return;
     for (int i = threadIdx.x; i < c.n; i += 256) {
         const float g = c.g[i] * coef;
         float p = c.p[i] * (1.0f - lr * c.wd);

@@ -14,8 +14,13 @@ model is a drop-in for ``tools/run_net.py``:
 
 Data loaders are whatever the caller provides (the reference's dataset code is out of scope): any iterable with ``len()`` that
 yields ``(inputs, labels, index, meta)`` with ``inputs`` a list of one ``[B,3,T,H,W]`` tensor, as the reference's loaders do.
-Pinned by tests/golden/train_loop.json (generated from the reference's metrics / logging / checkpoint / lr_policy modules); the
-meter classes follow meters.py's text (that module does not import without the dataset stack).
+Pinned by tests/golden/train_loop.json (generated from the reference's metrics / logging / checkpoint / lr_policy modules).
+The meter classes (aicity_action_amd/meters.py) keep the reference's public names and log lines only.
+
+Host / device overlap: the reference reads three scalars back with ``.item()`` every iteration (train_net.py:290-294), which
+drains the GPU queue once per step.  Here the three scalars go through ``meters.DeviceScalarQueue`` (non-blocking copy to
+pinned memory + event, absorbed one iteration late; a blocking read only on ``LOG_PERIOD`` lines and at the end of the epoch),
+so the loop keeps the step time ``bench.py --mode train`` measures (``bench.py --mode loop`` times exactly this function).
 """
 import datetime
 import decimal
@@ -24,9 +29,6 @@ import logging
 import math
 import os
 import time
-from collections import deque
-
-import numpy as np
 import torch
 
 from . import distributed as du
@@ -83,230 +85,8 @@ def cpu_mem_usage():
     return (vm.total - vm.available) / 1024 ** 3, vm.total / 1024 ** 3
 
 
-class _Timer(object):
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self._t0 = time.perf_counter()
-        self._paused = None
-
-    def pause(self):
-        if self._paused is None:
-            self._paused = time.perf_counter()
-
-    def seconds(self):
-        end = self._paused if self._paused is not None else time.perf_counter()
-        return end - self._t0
-
-
-class ScalarMeter(object):
-    """Windowed scalar tracker (meters.py:482-527): median / mean of the last ``window_size`` values, global mean."""
-
-    def __init__(self, window_size):
-        self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
-
-    def reset(self):
-        self.deque.clear()
-        self.total = 0.0
-        self.count = 0
-
-    def add_value(self, value):
-        self.deque.append(value)
-        self.count += 1
-        self.total += value
-
-    def get_win_median(self):
-        return float(np.median(self.deque))
-
-    def get_win_avg(self):
-        return float(np.mean(self.deque))
-
-    def get_global_avg(self):
-        return self.total / self.count
-
-
-class _IterTimers(object):
-    def __init__(self):
-        self.iter_timer, self.data_timer, self.net_timer = _Timer(), _Timer(), _Timer()
-
-    def iter_tic(self):
-        self.iter_timer.reset()
-        self.data_timer.reset()
-
-    def iter_toc(self):
-        self.iter_timer.pause()
-        self.net_timer.pause()
-
-    def data_toc(self):
-        self.data_timer.pause()
-        self.net_timer.reset()
-
-
-class TrainMeter(_IterTimers):
-    """Training stats (meters.py:529-676)."""
-
-    def __init__(self, epoch_iters, cfg):
-        super().__init__()
-        self._cfg = cfg
-        self.epoch_iters = epoch_iters
-        self.overall_iters = epoch_iters
-        self.MAX_EPOCH = cfg.SOLVER.MAX_EPOCH * epoch_iters
-        self.loss = ScalarMeter(cfg.LOG_PERIOD)
-        self.mb_top1_err = ScalarMeter(cfg.LOG_PERIOD)
-        self.mb_top5_err = ScalarMeter(cfg.LOG_PERIOD)
-        self.reset()
-
-    def reset(self):
-        self.loss.reset()
-        self.loss_total = 0.0
-        self.lr = None
-        self.mb_top1_err.reset()
-        self.mb_top5_err.reset()
-        self.num_top1_mis = 0
-        self.num_top5_mis = 0
-        self.num_samples = 0
-
-    def update_stats(self, top1_err, top5_err, loss, lr, mb_size):
-        self.loss.add_value(loss)
-        self.lr = lr
-        self.loss_total += loss * mb_size
-        self.num_samples += mb_size
-        if not self._cfg.DATA.MULTI_LABEL:
-            self.mb_top1_err.add_value(top1_err)
-            self.mb_top5_err.add_value(top5_err)
-            self.num_top1_mis += top1_err * mb_size
-            self.num_top5_mis += top5_err * mb_size
-
-    def log_iter_stats(self, cur_epoch, cur_iter):
-        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
-            return None
-        stats = {"_type": "train_iter", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
-                 "iter": "{}/{}".format(cur_iter + 1, self.epoch_iters), "loss": self.loss.get_win_median(), "lr": self.lr,
-                 "gpu_mem": "{:.2f}G".format(gpu_mem_usage())}
-        if not self._cfg.DATA.MULTI_LABEL:
-            stats["top1_err"] = self.mb_top1_err.get_win_median()
-            stats["top5_err"] = self.mb_top5_err.get_win_median()
-        return log_json_stats(stats) if du.get_rank() == 0 else None
-
-    def log_epoch_stats(self, cur_epoch):
-        stats = {"_type": "train_epoch", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH), "lr": self.lr,
-                 "gpu_mem": "{:.2f}G".format(gpu_mem_usage()), "RAM": "{:.2f}/{:.2f}G".format(*cpu_mem_usage()),
-                 "loss": self.loss_total / self.num_samples}
-        if not self._cfg.DATA.MULTI_LABEL:
-            stats["top1_err"] = self.num_top1_mis / self.num_samples
-            stats["top5_err"] = self.num_top5_mis / self.num_samples
-        return log_json_stats(stats) if du.get_rank() == 0 else None
-
-
-class ValMeter(_IterTimers):
-    """Validation stats (meters.py:694-933), single-label branch."""
-
-    def __init__(self, max_iter, cfg):
-        super().__init__()
-        self._cfg = cfg
-        self.max_iter = max_iter
-        self.overall_iters = max_iter
-        self.mb_top1_err = ScalarMeter(cfg.LOG_PERIOD)
-        self.mb_top5_err = ScalarMeter(cfg.LOG_PERIOD)
-        self.min_top1_err = 100.0
-        self.min_top5_err = 100.0
-        self.reset()
-
-    def reset(self):
-        self.iter_timer.reset()
-        self.mb_top1_err.reset()
-        self.mb_top5_err.reset()
-        self.num_top1_mis = 0
-        self.num_top5_mis = 0
-        self.num_samples = 0
-        self.all_preds = []
-        self.all_labels = []
-
-    def update_stats(self, top1_err, top5_err, mb_size):
-        self.mb_top1_err.add_value(top1_err)
-        self.mb_top5_err.add_value(top5_err)
-        self.num_top1_mis += top1_err * mb_size
-        self.num_top5_mis += top5_err * mb_size
-        self.num_samples += mb_size
-
-    def update_predictions(self, preds, labels):
-        self.all_preds.append(preds)
-        self.all_labels.append(labels)
-
-    def log_iter_stats(self, cur_epoch, cur_iter):
-        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
-            return None
-        stats = {"_type": "val_iter", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
-                 "iter": "{}/{}".format(cur_iter + 1, self.max_iter), "gpu_mem": "{:.2f}G".format(gpu_mem_usage()),
-                 "top1_err": self.mb_top1_err.get_win_median(), "top5_err": self.mb_top5_err.get_win_median()}
-        return log_json_stats(stats) if du.get_rank() == 0 else None
-
-    def log_epoch_stats(self, cur_epoch):
-        """Logs the ``val_epoch`` line and returns the top-5 error (the reference's ``eval_result``)."""
-        top1_err = self.num_top1_mis / self.num_samples
-        top5_err = self.num_top5_mis / self.num_samples
-        self.min_top1_err = min(self.min_top1_err, top1_err)
-        self.min_top5_err = min(self.min_top5_err, top5_err)
-        stats = {"_type": "val_epoch", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
-                 "gpu_mem": "{:.2f}G".format(gpu_mem_usage()), "RAM": "{:.2f}/{:.2f}G".format(*cpu_mem_usage()),
-                 "top1_err": top1_err, "top5_err": top5_err, "min_top1_err": self.min_top1_err, "min_top5_err": self.min_top5_err}
-        if du.get_rank() == 0:
-            log_json_stats(stats)
-        return top5_err
-
-
-class TestMeter(_IterTimers):
-    """Multi-view ensemble for testing (meters.py:277-482): ``num_clips`` predictions per video are summed (or max-ed)."""
-
-    def __init__(self, num_videos, num_clips, num_cls, overall_iters, ensemble_method="sum"):
-        super().__init__()
-        self.num_clips = num_clips
-        self.overall_iters = overall_iters
-        self.ensemble_method = ensemble_method
-        self.video_preds = torch.zeros((num_videos, num_cls))
-        self.video_labels = torch.zeros((num_videos)).long()
-        self.clip_count = torch.zeros((num_videos)).long()
-        self.stats = {}
-
-    def reset(self):
-        self.clip_count.zero_()
-        self.video_preds.zero_()
-        self.video_labels.zero_()
-
-    def update_stats(self, preds, labels, clip_ids):
-        for ind in range(preds.shape[0]):
-            vid_id = int(clip_ids[ind]) // self.num_clips
-            if self.video_labels[vid_id].sum() > 0:
-                assert torch.equal(self.video_labels[vid_id].float(), labels[ind].float())
-            self.video_labels[vid_id] = labels[ind]
-            if self.ensemble_method == "sum":
-                self.video_preds[vid_id] += preds[ind]
-            elif self.ensemble_method == "max":
-                self.video_preds[vid_id] = torch.max(self.video_preds[vid_id], preds[ind])
-            else:
-                raise NotImplementedError("Ensemble Method {} is not supported".format(self.ensemble_method))
-            self.clip_count[vid_id] += 1
-
-    def log_iter_stats(self, cur_iter):
-        eta_sec = self.iter_timer.seconds() * (self.overall_iters - cur_iter)
-        stats = {"split": "test_iter", "cur_iter": "{}".format(cur_iter + 1), "overall_iters": self.overall_iters,
-                 "eta": str(datetime.timedelta(seconds=int(eta_sec))), "time_diff": self.iter_timer.seconds()}
-        return log_json_stats(stats) if du.get_rank() == 0 else None
-
-    def finalize_metrics(self, ks=(1, 5)):
-        if not all(self.clip_count == self.num_clips):
-            logger.warning("clip count {} != num clips {}".format(
-                ", ".join("{}: {}".format(i, k) for i, k in enumerate(self.clip_count.tolist()) if k != self.num_clips), self.num_clips))
-        self.stats = {"split": "test_final"}
-        num_topks_correct = topks_correct(self.video_preds, self.video_labels, ks)
-        for k, x in zip(ks, num_topks_correct):
-            self.stats["top{}_acc".format(k)] = "{:.{prec}f}".format(float(x / self.video_preds.size(0)) * 100.0, prec=2)
-        if du.get_rank() == 0:
-            log_json_stats(self.stats)
-        return self.stats
+# the statistics classes live in meters.py (own design: column ring + weighted sums, non-blocking device-scalar queue)
+from .meters import DeviceScalarQueue, ScalarMeter, TestMeter, TrainMeter, ValMeter  # noqa: E402,F401
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -439,7 +219,12 @@ def check_nan_losses(loss):
 
 
 def train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, cfg):
-    """One training epoch in the reference's step order (train_net.py:35-324, single-label branch)."""
+    """One training epoch in the reference's step order (train_net.py:35-324, single-label branch).
+
+    NaN handling: the reference raises on a NaN loss BEFORE ``backward()`` (train_net.py:221-223) at the price of a host sync
+    per iteration.  Here the optimizer step itself is guarded on the device -- the fused clip + AdamW kernels skip the update
+    when the loss-derived gradient norm is not finite (solver.HipAdamW.step) -- and the ``RuntimeError`` is raised when the
+    iteration's scalars reach the host (at most ``HIP.STAT_QUEUE_DEPTH`` iterations later), with the parameters still clean."""
     model.train()
     train_meter.iter_tic()
     data_size = len(train_loader)
@@ -459,17 +244,14 @@ def train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, 
             scaler.update()
         else:
             loss.backward()
-            optimizer.step()                # global-norm clip (SOLVER.CLIP_GRAD_L2NORM) + AdamW, fused
+            optimizer.step()                # global-norm clip (SOLVER.CLIP_GRAD_L2NORM) + AdamW, fused; skipped on a non-finite norm
         lab_idx = labels if labels.dim() == 1 else labels.argmax(1)
         n1, n5 = topks_correct(preds.detach(), lab_idx, (1, 5))
-        top1_err = (1.0 - n1 / preds.size(0)) * 100.0
-        top5_err = (1.0 - n5 / preds.size(0)) * 100.0
-        loss_d = loss.detach()
+        stats = torch.stack([loss.detach().float().reshape(()), (1.0 - n1 / preds.size(0)) * 100.0,
+                             (1.0 - n5 / preds.size(0)) * 100.0])                          # [loss, top1_err, top5_err]
         if world > 1:
-            loss_d, top1_err, top5_err = du.all_reduce([loss_d, top1_err, top5_err])      # one collective
-        loss_v, top1_v, top5_v = torch.stack([loss_d.float().reshape(()), top1_err.reshape(()), top5_err.reshape(())]).tolist()
-        check_nan_losses(loss_v)            # the reference checks before backward; here the one host sync of the iteration
-        train_meter.update_stats(top1_v, top5_v, loss_v, lr, inputs[0].size(0) * max(world, 1))
+            stats = du.all_reduce([stats])[0]                                              # one collective (train_net.py:284-287)
+        train_meter.update_stats_async(stats, lr, inputs[0].size(0) * max(world, 1))       # no host sync here
         train_meter.iter_toc()
         train_meter.log_iter_stats(cur_epoch, cur_iter)
         train_meter.iter_tic()
@@ -490,13 +272,11 @@ def eval_epoch(val_loader, model, val_meter, cur_epoch, cfg):
         preds = model(inputs)
         lab_idx = labels if labels.dim() == 1 else labels.argmax(1)
         n1, n5 = topks_correct(preds, lab_idx, (1, 5))
-        top1_err = (1.0 - n1 / preds.size(0)) * 100.0
-        top5_err = (1.0 - n5 / preds.size(0)) * 100.0
+        stats = torch.stack([(1.0 - n1 / preds.size(0)) * 100.0, (1.0 - n5 / preds.size(0)) * 100.0])
         if world > 1:
-            top1_err, top5_err = du.all_reduce([top1_err, top5_err])
-        top1_v, top5_v = torch.stack([top1_err.reshape(()), top5_err.reshape(())]).tolist()
+            stats = du.all_reduce([stats])[0]
         val_meter.iter_toc()
-        val_meter.update_stats(top1_v, top5_v, inputs[0].size(0) * max(world, 1))
+        val_meter.update_stats_async(stats, inputs[0].size(0) * max(world, 1))
         val_meter.update_predictions(preds, labels)
         val_meter.log_iter_stats(cur_epoch, cur_iter)
         val_meter.iter_tic()
@@ -518,7 +298,7 @@ def perform_test(test_loader, model, test_meter, cfg):
         if du.get_world_size() > 1:
             preds, labels, video_idx = du.all_gather_cat(preds), du.all_gather_cat(labels), du.all_gather_cat(video_idx)
         test_meter.iter_toc()
-        test_meter.update_stats(preds.detach().float().cpu(), labels.detach().cpu(), video_idx.detach().cpu())
+        test_meter.update_stats(preds, labels, video_idx)
         test_meter.log_iter_stats(cur_iter)
         test_meter.iter_tic()
     return test_meter.finalize_metrics()
@@ -529,8 +309,12 @@ def train(cfg, model, train_loader, val_loader=None, optimizer=None, scaler=None
     optimizer = optimizer if optimizer is not None else solver.construct_optimizer(model, cfg)
     if scaler is None:
         # train_net.py:634: GradScaler(enabled=cfg.TRAIN.MIXED_PRECISION); only the fp16 arithmetic needs the loss scale
+        # (fp16 gradients underflow without one, so HIP.PRECISION fp16 always trains with the scaler -- the reference's fp16
+        # recipes set TRAIN.MIXED_PRECISION True; bf16 / fp32 never need it)
         fp16 = getattr(getattr(cfg, "HIP", None), "PRECISION", "bf16") == "fp16"
-        scaler = solver.HipGradScaler(enabled=bool(cfg.TRAIN.MIXED_PRECISION) and fp16)
+        if fp16 and not cfg.TRAIN.MIXED_PRECISION:
+            logger.warning("HIP.PRECISION fp16 without TRAIN.MIXED_PRECISION: enabling the loss scaler anyway")
+        scaler = solver.HipGradScaler(enabled=fp16)
     start_epoch = load_train_checkpoint(cfg, model, optimizer, scaler if scaler.is_enabled() else None)
     train_meter = TrainMeter(len(train_loader), cfg)
     val_meter = ValMeter(len(val_loader), cfg) if val_loader is not None else None

@@ -48,8 +48,8 @@ def param_groups(model, cfg):
             if not p.requires_grad:
                 continue
             full = (name + "." if name else "") + pname
-            if name in skip or full in skip:
-                no_decay.append((full, p))
+            if name in skip:                 # the reference tests the MODULE name only (optimizer.py:69): with
+                no_decay.append((full, p))   # MVIT.ZERO_DECAY_POS_CLS the root-level pos_embed_* parameters still decay there
             elif cfg.SOLVER.ZERO_WD_1D_PARAM and (p.ndim == 1 or name.endswith(".bias")):
                 no_decay.append((full, p))
             else:
@@ -97,7 +97,10 @@ class HipAdamW(object):
         rec, ptrs = [], []
         for grp in self.groups:
             for p in grp["params"]:
-                assert p.grad is not None and p.grad.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
+                if p.grad is None:            # torch.optim skips parameters that received no gradient this step
+                    ptrs.append(0)
+                    continue
+                assert p.grad.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
                 m, v = self.state[p]
                 n = p.numel()
                 ptrs.append(p.grad.data_ptr())
@@ -110,6 +113,10 @@ class HipAdamW(object):
         # With set_to_none the gradient addresses change every step, so this runs every step: the table goes up through a small
         # ring of PINNED host buffers with a non-blocking copy (a copy from pageable memory blocks the host until the stream has
         # drained -- one full sync per training step).  The kernels that read the table are ordered behind the copy on the stream.
+        if not rec:
+            self._n = 0
+            self._grad_ptrs = ptrs
+            return
         ring = self.__dict__.get("_pin_ring")
         if ring is None or ring[0][0].numel() != host.size or self._table is None or self._table.device != dev:
             ring = [[torch.empty(host.size, dtype=torch.uint8).pin_memory(), None] for _ in range(3)]
@@ -132,10 +139,14 @@ class HipAdamW(object):
     def step(self, max_norm=None, grad_scale=None):
         """One clipped AdamW step.  max_norm None -> cfg.SOLVER.CLIP_GRAD_L2NORM (None/0 disables clipping).
         grad_scale (float): the gradients carry this loss-scale factor (HipGradScaler): they are unscaled inside the fused
-        update, the clip acts on the unscaled norm, and the step is SKIPPED (returns None) when the norm is inf / nan."""
+        update, the clip acts on the unscaled norm, and the step is SKIPPED (returns None) when the norm is inf / nan.
+        Without a scaler the same guard sits in the AdamW kernel: a non-finite global norm leaves parameters and moments
+        untouched (the loop raises on the NaN loss when the iteration's scalars reach the host, engine.train_epoch)."""
         cur = [p.grad.data_ptr() if p.grad is not None else 0 for grp in self.groups for p in grp["params"]]
         if self._table is None or cur != self._grad_ptrs:
             self._build()                                   # grads were re-allocated (e.g. set_to_none): refresh the table
+        if self._n == 0:
+            return None
         if max_norm is None:
             max_norm = self.cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0
         L = _hip.lib()

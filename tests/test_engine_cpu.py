@@ -118,3 +118,47 @@ def test_test_meter_view_sum_ensemble():
     st = tm.finalize_metrics(ks=(1, 2))
     assert st == {"split": "test_final", "top1_acc": "50.00", "top2_acc": "100.00"}
     assert torch.allclose(tm.video_preds[0], preds[:3].sum(0)) and tm.clip_count.tolist() == [3, 3]
+
+
+def test_device_scalar_queue_and_async_meter_on_host_tensors():
+    """The non-blocking statistics path with CPU tensors (no GPU here): rows pass straight through, in order; the async entry
+    point of TrainMeter gives the same log lines as the float one; a NaN loss raises when its row is absorbed."""
+    from aicity_action_amd.meters import DeviceScalarQueue
+    q = DeviceScalarQueue(3, depth=2)
+    for i in range(5):
+        q.put(torch.tensor([float(i), 2.0 * i, 3.0 * i]), ("tag", i))
+    rows = q.ready()
+    assert [t for _, t in rows] == [("tag", i) for i in range(5)] and [float(r[1]) for r, _ in rows] == [0.0, 2.0, 4.0, 6.0, 8.0]
+    assert q.ready(wait=True) == []
+    cfg = get_cfg()
+    cfg.LOG_PERIOD, cfg.SOLVER.MAX_EPOCH = 2, 5
+    a, b = engine.TrainMeter(4, cfg), engine.TrainMeter(4, cfg)
+    data = [(100.0, 50.0, 3.0), (50.0, 0.0, 1.0), (0.0, 0.0, 2.0), (100.0, 100.0, 4.0)]
+    for it, (e1, e5, loss) in enumerate(data):
+        a.update_stats(e1, e5, loss, 1e-4, 8)
+        b.update_stats_async(torch.tensor([loss, e1, e5]), 1e-4, 8)
+        la, lb = a.log_iter_stats(0, it), b.log_iter_stats(0, it)
+        if la is not None:
+            la, lb = json.loads(la.split("json_stats: ")[1]), json.loads(lb.split("json_stats: ")[1])
+            la.pop("gpu_mem"), lb.pop("gpu_mem")
+            assert la == lb
+    ea, eb = [json.loads(m.log_epoch_stats(0).split("json_stats: ")[1]) for m in (a, b)]
+    assert (ea["loss"], ea["top1_err"], ea["top5_err"]) == (eb["loss"], eb["top1_err"], eb["top5_err"]) == (2.5, 62.5, 37.5)
+    c = engine.TrainMeter(4, cfg)
+    with pytest.raises(RuntimeError, match="NaN losses"):
+        c.update_stats_async(torch.tensor([float("nan"), 0.0, 0.0]), 1e-4, 8)
+    s = engine.ScalarMeter(2)
+    for v in (1.0, 5.0, 3.0):
+        s.add_value(v)
+    assert (s.get_win_median(), s.get_win_avg(), s.get_global_avg(), s.count) == (4.0, 4.0, 3.0, 3)
+
+
+def test_test_meter_max_ensemble_and_label_consistency():
+    tm = engine.TestMeter(num_videos=2, num_clips=2, num_cls=3, overall_iters=1, ensemble_method="max")
+    preds = torch.tensor([[0.2, 0.7, 0.1], [0.6, 0.3, 0.1], [0.1, 0.1, 0.8], [0.3, 0.3, 0.4]])
+    tm.update_stats(preds, torch.tensor([1, 1, 2, 2]), torch.tensor([0, 1, 2, 3]))
+    assert torch.allclose(tm.video_preds, torch.tensor([[0.6, 0.7, 0.1], [0.3, 0.3, 0.8]]))
+    with pytest.raises(AssertionError):
+        tm.update_stats(preds[:1], torch.tensor([2]), torch.tensor([0]))          # video 0 was labelled 1
+    with pytest.raises(NotImplementedError):
+        engine.TestMeter(1, 1, 3, 1, ensemble_method="mean")

@@ -150,26 +150,40 @@ def test_perform_test_view_sum(tmp_path):
     assert torch.allclose(tm.video_preds.sum(1), torch.full((2,), float(B)), atol=1e-3)      # softmax scores summed over views
 
 
-def _grads_for(meta, precision, tmp, clip, labels, act_ckpt=False, scale=None):
+def _grads_for(meta, precision, tmp, clip, labels, act_ckpt=False, scale=None, probe=None):
+    from aicity_action_amd.autograd import _BlockFn
     cfg, model = _make(meta, precision, tmp)
     cfg.MODEL.ACT_CHECKPOINT = act_ckpt
     if act_ckpt:
         cfg2, model = _make(meta, precision, tmp)
         model.use_act_checkpoint = True
     model.train()
+    torch.cuda.synchronize()
+    n0, m0 = _BlockFn.forward_launches, torch.cuda.memory_allocated()
     logits = model([clip])
     loss = engine._loss(cfg, logits, labels)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - m0            # what the autograd graph keeps alive between forward and backward
+    n_fwd = _BlockFn.forward_launches - n0
     (loss * scale if scale else loss).backward()
+    if probe is not None:
+        probe.update(held=held, fwd_in_forward=n_fwd, fwd_total=_BlockFn.forward_launches - n0, depth=len(model.blocks))
     return model, loss.item(), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
 
 
 def test_activation_checkpointing_gives_the_same_gradients(tmp_path):
-    """MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037): block forwards are re-run inside backward."""
+    """MODEL.ACT_CHECKPOINT (video_model_builder.py:1036-1037): only the block inputs are kept, every block's forward kernels run
+    a second time inside backward (counted), the memory held between forward and backward drops, gradients are unchanged."""
     _, meta = load_golden("tiny_even")
     clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], 5).cuda()
     labels = torch.tensor([1, 7]).cuda()
-    _, l0, g0 = _grads_for(meta, "fp32", str(tmp_path), clip, labels)
-    _, l1, g1 = _grads_for(meta, "fp32", str(tmp_path), clip, labels, act_ckpt=True)
+    p0, p1 = {}, {}
+    _, l0, g0 = _grads_for(meta, "fp32", str(tmp_path), clip, labels, probe=p0)
+    _, l1, g1 = _grads_for(meta, "fp32", str(tmp_path), clip, labels, act_ckpt=True, probe=p1)
+    assert p0["fwd_in_forward"] == p0["depth"] and p0["fwd_total"] == p0["depth"]
+    assert p1["fwd_in_forward"] == p1["depth"] and p1["fwd_total"] == 2 * p1["depth"]          # re-run once per block in backward
+    print("activations held between forward and backward: %.2f MB plain, %.2f MB checkpointed" % (p0["held"] / 2 ** 20, p1["held"] / 2 ** 20))
+    assert p1["held"] < 0.5 * p0["held"]
     assert abs(l0 - l1) <= 1e-6
     for k in g0:
         assert (g0[k] - g1[k]).abs().max().item() <= 1e-5 * max(1.0, g0[k].abs().max().item()), k

@@ -78,8 +78,12 @@ def test_bf16_train_step_is_close_to_reference(name):
 
 
 def test_drop_path_and_dropout_statistics():
-    """Stochastic ops: with DROPPATH_RATE/DROPOUT on, outputs differ run to run in train mode, are deterministic in
-    eval mode, and the per-sample drop-path factor takes only the values {0, 1/keep}."""
+    """Stochastic ops (common.py:46-59, head_helper.py:410-411): outputs differ run to run in train mode and are deterministic
+    in eval mode; the per-sample drop-path factor of block i takes only the values {0, 1/keep_i} with keep_i = 1 - 0.4*i/(depth-1)
+    (video_model_builder.py:880-882; block 0 is never dropped), its empirical keep rate matches keep_i, its mean is 1 (the branch
+    is unbiased), the two draws of a block (attention / MLP branch) are independent, and the head-dropout mask takes {0, 1/(1-p)}
+    at rate 1-p."""
+    from aicity_action_amd.autograd import _draw_train_noise
     z, meta = load_golden("tiny_even")
     cfg = cfg_for_case(meta, "fp32")
     cfg.NUM_GPUS = 1
@@ -90,10 +94,37 @@ def test_drop_path_and_dropout_statistics():
     with torch.no_grad():
         a, b = model([clip]), model([clip])
     assert not torch.equal(a, b)
+    depth = len(model.geoms)
+    rates = [g.drop_path for g in model.geoms]
+    assert rates[0] == 0.0 and abs(rates[-1] - cfg.MVIT.DROPPATH_RATE) < 1e-12
+    assert all(abs(r - cfg.MVIT.DROPPATH_RATE * i / (depth - 1)) < 1e-12 for i, r in enumerate(rates))
+    torch.manual_seed(7)
+    B = 4096
+    dp, mask = _draw_train_noise(model, B, model.geoms[-1].dim_out, clip.device)
+    assert dp.shape == (depth, 2, B)
+    for i, r in enumerate(rates):
+        keep = 1.0 - r
+        f = dp[i]
+        vals = torch.unique(f)
+        allowed = torch.tensor([0.0, 1.0 / keep], device=f.device)
+        assert all(bool((v - allowed).abs().min() <= 1e-6) for v in vals), (i, vals)
+        rate = (f > 0).float().mean().item()
+        assert abs(rate - keep) <= 4.0 * (keep * (1 - keep) / (2 * B)) ** 0.5 + 1e-9, (i, rate, keep)
+        assert abs(f.mean().item() - 1.0) <= 0.06
+        if 0.0 < r:
+            both = ((f[0] > 0) & (f[1] > 0)).float().mean().item()      # independent draws: P(both kept) = keep^2
+            assert abs(both - keep * keep) <= 0.04, (i, both)
+    p = model.head_dropout
+    assert p == cfg.MODEL.DROPOUT_RATE and mask.shape == (B, model.geoms[-1].dim_out)
+    mv = torch.unique(mask)
+    assert mv.numel() == 2 and abs(mv[0].item()) == 0.0 and abs(mv[1].item() - 1.0 / (1.0 - p)) <= 1e-6
+    assert abs((mask > 0).float().mean().item() - (1.0 - p)) <= 0.01
     model.eval()
     with torch.no_grad():
         c, d = model([clip]), model([clip])
     assert torch.equal(c, d) and torch.allclose(c.sum(1), torch.ones(2, device=c.device), atol=1e-5)
+    dp_e, mask_e = _draw_train_noise(model, 4, model.geoms[-1].dim_out, clip.device)
+    assert dp_e is None and mask_e is None                               # eval: identity, no draws
 
 
 def _full_train_step(name, precision):
@@ -121,15 +152,28 @@ def test_full_size_fp32_train_step_matches_reference_golden(name):
     assert np.abs(logits.cpu().numpy() - z["train.logits"]).max() <= 1e-4
     assert abs(loss - float(z["train.loss"])) <= 1e-5
     assert abs(tot - float(z["train.grad_norm_fp64"])) <= 1e-4 * tot
-    worst = 0.0
+    worst, worst_own, worst_own_name = 0.0, 0.0, ""
+    lr = float(z["train.lr"])
     for k, p in model.named_parameters():
-        gref = z["grad." + k]
+        gref = z["grad." + k]                              # post-clip: |g| = 1 over 35 M elements, so single elements are ~1e-5
         got = sample_like(grads[k] * coef, z["gmom." + k])
-        err = np.abs(got - gref).max() / max(1.0, np.abs(gref).max())
-        worst = max(worst, err)
-        assert err <= 1e-4, (k, err)
-        assert np.abs(sample_like(p, z["gmom." + k]) - z["step." + k]).max() <= 5e-6, k
-    print("[%s fp32 train] loss %.6f |g| %.4f worst relative gradient error %.2e" % (name, loss, tot, worst))
+        gmax = float(np.abs(gref).max())
+        err = np.abs(got - gref).max()
+        worst = max(worst, err / max(1.0, gmax))
+        assert err <= 1e-4 * max(1.0, gmax), (k, err)      # the bound of the tiny cases
+        if gmax > 1e-9:                                    # ... and relative to the tensor's own largest gradient
+            own = err / gmax
+            if own > worst_own:
+                worst_own, worst_own_name = own, k
+        # AdamW step 1 moves every element by lr * g / (|g| + eps) = +-lr: compare where the reference gradient is far above
+        # the kernels' error, so its sign (hence the whole update) is determined
+        sure = np.abs(gref) > 0.05 * gmax
+        d = np.abs(sample_like(p, z["gmom." + k]) - z["step." + k])
+        assert d[sure].max(initial=0.0) <= 5e-6, k
+        assert d.max() <= 2.0 * lr + 5e-6, k
+    print("[%s fp32 train] loss %.6f |g| %.4f worst gradient error %.2e (relative to max(1, max|g|)), %.2e relative to the tensor's own max|g| (%s)"
+          % (name, loss, tot, worst, worst_own, worst_own_name))
+    assert worst_own <= 2e-3, (worst_own_name, worst_own)
 
 
 @pytest.mark.parametrize("name", ["full224", "full448"])

@@ -123,3 +123,56 @@ def test_capi_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS), (declared ^ set(_hip.EXPORTS))
     assert _hip.lib().mvit_version().decode().startswith("mvit-hip")
     assert _hip.lib().mvit_strerror(-4).decode()
+
+
+def test_init_weights_distributions():
+    """a15: MViT._init_weights / trunc_normal_ (video_model_builder.py:1046-1055,1126-1133).  Every nn.Linear weight and the
+    two position embeddings ~ N(0, 0.02) truncated at the ABSOLUTE bounds +-2 (trunc_normal_'s a/b defaults: 100 sigma, so
+    effectively untruncated) with zero bias; LayerNorm weight 1 / bias 0; Conv3d (stem, depthwise pools) keep torch's default
+    kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)), the stem bias likewise."""
+    torch.manual_seed(1234)
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"), ["NUM_GPUS", 0])
+    m = MViT(cfg)
+    lin_w = []
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.Linear):
+            w = mod.weight.detach()
+            assert w.abs().max().item() <= 2.0 and float(mod.bias.detach().abs().max()) == 0.0, name
+            if w.numel() >= 96 * 96:
+                assert abs(w.std().item() - 0.02) <= 0.0015 and abs(w.mean().item()) <= 0.002, (name, w.std().item())
+            lin_w.append(w.flatten())
+        elif isinstance(mod, torch.nn.LayerNorm):
+            assert bool((mod.weight == 1).all()) and bool((mod.bias == 0).all()), name
+        elif isinstance(mod, torch.nn.Conv3d):
+            fan_in = mod.weight.shape[1] * mod.weight.shape[2] * mod.weight.shape[3] * mod.weight.shape[4]
+            bound = 1.0 / fan_in ** 0.5
+            w = mod.weight.detach()
+            assert w.abs().max().item() <= bound + 1e-7, name
+            # uniform on [-bound, bound]: std = bound / sqrt(3); checked on the tensors large enough for the estimate
+            if w.numel() >= 2000:
+                assert abs(w.std().item() / (bound / 3 ** 0.5) - 1.0) <= 0.05, (name, w.std().item(), bound)
+            if mod.bias is not None:
+                assert mod.bias.detach().abs().max().item() <= bound + 1e-7, name
+    allw = torch.cat(lin_w)
+    assert abs(allw.std().item() - 0.02) <= 2e-4 and abs(allw.mean().item()) <= 2e-5
+    # N(0, 0.02): 4.55 % of the mass beyond 2 sigma, 0.27 % beyond 3 sigma -- a +-2 sigma truncation would show here
+    frac2 = (allw.abs() > 0.04).float().mean().item()
+    frac3 = (allw.abs() > 0.06).float().mean().item()
+    assert abs(frac2 - 0.0455) <= 0.002 and abs(frac3 - 0.0027) <= 0.0005, (frac2, frac3)
+    for pe in (m.pos_embed_spatial, m.pos_embed_temporal):
+        assert abs(pe.detach().std().item() - 0.02) <= (0.001 if pe.numel() > 10000 else 0.004)
+    # the 224 config: 34,415,538 parameters (SURVEY.md section 0.3)
+    assert sum(p.numel() for p in m.parameters()) == 34415538
+
+
+def test_no_weight_decay_grouping_follows_the_module_name_rule():
+    """optimizer.py:56-75 tests the MODULE name against model.no_weight_decay(): with MVIT.ZERO_DECAY_POS_CLS True the
+    root-level pos_embed_* parameters (module name "") therefore stay in the decay group, exactly as in the reference, and the
+    [decay..., no-decay...] index order of AdamW.state_dict() is unchanged."""
+    from aicity_action_amd.solver import param_groups
+    for flag in (False, True):
+        cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"), ["NUM_GPUS", 0, "MVIT.ZERO_DECAY_POS_CLS", flag])
+        m = MViT(cfg)
+        decay, no_decay = param_groups(m, cfg)
+        assert (len(decay), len(no_decay)) == (119, 231)
+        assert {"pos_embed_spatial", "pos_embed_temporal"} <= {n for n, _ in decay}
