@@ -55,6 +55,21 @@ def build_model(cfg, gpu_id=None):
         cur_device = torch.cuda.current_device() if gpu_id is None else gpu_id
         model = model.cuda(device=cur_device)
     if cfg.NUM_GPUS > 1:
-        model = torch.nn.parallel.DistributedDataParallel(
-            module=model, device_ids=[cur_device], output_device=cur_device)
+        model = wrap_ddp(model, cfg, cur_device)
+    return model
+
+
+def wrap_ddp(model, cfg, device):
+    """The reference's DistributedDataParallel wrap (build.py:47-54) with the knobs that matter on xGMI: gradients are views
+    into the all-reduce buckets (no copy in / out of the 141 MB payload), the graph is declared static (all 350 parameters
+    receive a gradient every step: no unused-parameter search, bucket order fixed after the first iteration), and optionally
+    (HIP.DDP_BF16_GRADS) the payload is compressed to bf16 for the all-reduce and decompressed into the fp32 gradients."""
+    hip = getattr(cfg, "HIP", None)
+    model = torch.nn.parallel.DistributedDataParallel(
+        module=model, device_ids=[device], output_device=device,
+        gradient_as_bucket_view=bool(getattr(hip, "DDP_BUCKET_VIEW", True)),
+        static_graph=bool(getattr(hip, "DDP_STATIC_GRAPH", True)))
+    if bool(getattr(hip, "DDP_BF16_GRADS", False)):
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        model.register_comm_hook(None, default_hooks.bf16_compress_hook)
     return model

@@ -10,13 +10,19 @@ generated on the device before the timed region; random-init weights from the se
       + backward + global-norm clip 1.0 + AdamW, fp32 master weights; N>1 = DistributedDataParallel over RCCL
       (one gradient all-reduce of 35.3 M fp32 per step, bucketed, overlapped with the per-block backward).
   --mode fwd: eval forward only (BASELINE configs[1]); clips sharded over ranks, no data-path collective.
+  --mode loop: the same train step driven by aicity_action_amd.engine.train_epoch (the reference's loop: per-iteration LR,
+      top-k errors, stat all-reduce, meters, json_stats lines) over a synthetic in-memory loader -- what a user of
+      tools/run_net.py gets; must stay within a few % of --mode train (no per-iteration host sync).
   --mode window: BASELINE configs[4]: sliding-window inference over a synthetic 30 s 540p stream x 3 camera views
       (57 windows of 16x4 frames per view, GPU gather + cv2-style resize to 448 + normalise + forward), the 171 windows
       sharded over the ranks and gathered ("strong" scaling: the stream is fixed).
 Per-GPU work is fixed as N grows ("weak" scaling); the timed region is bracketed by barrier +
-torch.cuda.synchronize() and the MAX over ranks is reported.  Rank 0 prints ONE JSON
-line with `roofline` (dominant kernel = fused attention, timed live with HIP events on the launch stream) and
-`cpu_baseline` (the oracle -- CPU restatement of the reference's unfused op sequence -- on the host cores).
+torch.cuda.synchronize() and the MAX over ranks is reported (wall clock over exactly K steps: the driver's contract; the
+median of per-step HIP-event intervals is given beside it as `ms_per_step_event_median`).  Rank 0 prints ONE JSON
+line with `roofline` (dominant kernel = fused attention, timed live with HIP events on the launch stream),
+`cpu_baseline` (the oracle -- CPU restatement of the reference's unfused op sequence -- on the host cores) and, in the default
+train mode, `forward`: the eval-forward record of BASELINE configs[1] (bf16 and fp16 MFMA builds: clips/s, fraction of the
+MFMA roofline -- the north star's 30 % target is on this number -- and the logit error against the reference's golden vector).
 """
 import argparse
 import copy
@@ -31,6 +37,8 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_CLIP = {448: 856.45, 224: 127.73}   # SURVEY.md section 8d (2 FLOP/MAC, GEMM + conv terms)
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+TRAFFIC_FWD = "r1_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh)
+TRAFFIC_BWD = "r1_attn_bwd_hbm_traffic.json"
 
 
 def attention_flops(geoms, B):
@@ -42,13 +50,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="train", choices=["train", "fwd", "window"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "window", "loop"])
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--streams", type=int, default=2, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-forward-record", action="store_true", help="train mode: skip the extra eval-forward timing")
     args = ap.parse_args()
 
     import torch
@@ -68,13 +77,17 @@ def main():
     dev_index = local_rank if local_rank < ndev else 0      # a launcher that narrows each rank's visibility to one GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("MVIT_BENCH_BACKEND", "nccl")      # "gloo": tests that run two ranks on ONE GPU (RCCL refuses that)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     yaml = "MVITV2_FULL_B_16x4_CONV_448.yaml" if args.crop == 448 else "MVITV2_FULL_B_16x4_CONV.yaml"
     cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision, "HIP.STREAMS", args.streams])
     mv = copy.deepcopy(cfg.MVIT.to_dict())
-    train = args.mode == "train"
+    train = args.mode in ("train", "loop")
     manual_ddp = False
     if train and world > 1:
         if world <= ndev:
@@ -83,7 +96,8 @@ def main():
             manual_ddp = True             # fewer visible devices than ranks: same wrap, applied here
     model = build_model(cfg, gpu_id=dev_index)
     if manual_ddp:
-        model = torch.nn.parallel.DistributedDataParallel(module=model, device_ids=[dev_index], output_device=dev_index)
+        from aicity_action_amd.models.build import wrap_ddp
+        model = wrap_ddp(model, cfg, dev_index)
     core = model.module if hasattr(model, "module") else model
     load_synth_weights(core, 0)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -99,6 +113,24 @@ def main():
         def step():
             res = [swc.run(v) for v in views]
             return torch.from_numpy(res[0][0][2])
+    elif args.mode == "loop":
+        import logging
+        from aicity_action_amd import engine
+        from aicity_action_amd.solver import construct_optimizer
+        logging.getLogger("aicity_action_amd.engine").setLevel(logging.WARNING)
+        model.train()
+        opt = construct_optimizer(model, cfg)
+        labels = torch.arange(args.batch, device=dev) % cfg.MODEL.NUM_CLASSES
+        cfg.LOG_PERIOD = 10                                             # configs/Aicity/*.yaml value
+
+        class _Loader(list):
+            pass
+
+        def run_epoch(n, epoch):
+            loader = _Loader([([clip], labels, torch.arange(args.batch), {})] * n)
+            engine.train_epoch(loader, model, opt, None, engine.TrainMeter(n, cfg), epoch, cfg)
+
+        step = None
     elif train:
         from aicity_action_amd.solver import construct_optimizer, get_lr_at_epoch, soft_target_cross_entropy
         model.train()
@@ -128,14 +160,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    ev_ms = None
+    if args.mode == "loop":
+        run_epoch(max(args.warmup, 1), 0)
+        barrier()
+        t0 = time.perf_counter()
+        run_epoch(args.steps, 1)
+        barrier()
+        dt = time.perf_counter() - t0
+        out = torch.zeros(1, device=dev)
+    else:
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(args.steps):
+            out = step()
+            evs[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        iv = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        ev_ms = iv[len(iv) // 2]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -197,14 +244,19 @@ def main():
                 del do, dq, dk, dv, ws
             del q, k, v, o, lse
 
-        def pmc_traffic(fname, key):
+        traffic_src = {}
+
+        def pmc_traffic(fname, key, tag):
             """HBM bytes per launch from the committed PMC measurement of this exact workload (tools/traffic.sh: rocprofv3 --pmc
-            FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None for any other configuration."""
+            FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None for any other configuration.  The file
+            records the commit of the kernels it was measured on (`measured_at_commit`), echoed here so staleness is visible."""
             path = os.path.join(ROOT, "profiles", fname)
             if not (args.batch == 8 and args.crop == 448 and args.precision == "bf16" and os.path.exists(path)):
                 return None
             try:
-                rec = json.load(open(path))["by_clips_per_launch"].get(str(args.batch // sub))
+                doc = json.load(open(path))
+                rec = doc["by_clips_per_launch"].get(str(args.batch // sub))
+                traffic_src[tag] = {"file": "profiles/" + fname, "measured_at_commit": doc.get("measured_at_commit", "unrecorded")}
                 return round(float(rec[key]), 0) if rec else None
             except Exception:
                 return None
@@ -216,62 +268,112 @@ def main():
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
         fwd_rl = rl("attn_fwd_pipe_kernel (%s)" % sfx if act else "attn_fwd_f32_kernel", sum(flops), fwd_ms, per_f,
-                    pmc_traffic("r1_attn_fwd_hbm_traffic.json", "traffic_bytes_per_launch"))
+                    pmc_traffic(TRAFFIC_FWD, "traffic_bytes_per_launch", "attention_fwd"))
         if train:
             roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b,
-                          pmc_traffic("r1_attn_bwd_hbm_traffic.json", "traffic_bytes_per_call"))
+                          pmc_traffic(TRAFFIC_BWD, "traffic_bytes_per_call", "attention_bwd"))
             extra_rooflines["roofline_attention_fwd"] = fwd_rl
         else:
             roofline = fwd_rl
+        roofline["traffic_source"] = traffic_src
 
-    # ---- CPU baseline: the oracle on the host cores, bounded sample ------------------------------------------
+    # ---- train mode: the eval-forward record of BASELINE configs[1] beside the headline (north star: >= 30 % on THIS number) ----
+    forward_rec = None
+    if args.mode == "train" and not args.no_forward_record and args.crop == 448:
+        import numpy as np
+        forward_rec = {}
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "mvit_full448.npz"))
+        gmeta = json.loads(bytes(gold["meta"]).decode())
+        from aicity_action_amd.utils.synth import synth_clip
+        gclip = synth_clip(1, 16, 448, gmeta["clip_seed"]).to(dev)
+        for prec in ("bf16", "fp16"):
+            cfg_f = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", prec, "HIP.STREAMS", args.streams])
+            mf = build_model(cfg_f, gpu_id=dev_index).eval()
+            load_synth_weights(mf, 0)
+            with torch.no_grad():
+                _, lg = mf._forward_hip(gclip, return_logits=True)
+                err = float(np.abs(lg.float().cpu().numpy() - gold["logits"]).max())
+                for _ in range(5):
+                    mf([clip])
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    mf([clip])
+                barrier()
+                fdt = time.perf_counter() - t0
+            ft = torch.tensor([fdt], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+            fdt = ft.item()
+            cps = world * args.batch * 20 / fdt
+            forward_rec[prec] = {"clips_per_s": round(cps, 2), "ms_per_step": round(fdt / 20 * 1e3, 4), "steps": 20, "warmup": 5,
+                                 "model_roofline_frac": round(cps / world * GFLOP_PER_CLIP[448] / 1e3 / PEAK_BF16_TFLOPS, 4),
+                                 "logit_err_vs_golden": float("%.3g" % err),
+                                 "golden": "tests/golden/mvit_full448.npz (reference CPU fp32 logits, B=1; gate 1e-3)"}
+            del mf
+        forward_rec["workload"] = "MViTv2-B 16x4 crop=448 eval forward, synthetic clips, BS=%d per GPU, HIP.STREAMS %d (BASELINE configs[1])" % (
+            args.batch, args.streams)
+        forward_rec["target_frac"] = 0.30
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (BASELINE.md section 4 as far as ~60 s allow) --------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and args.mode != "window":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import mvit_oracle as O
+        from aicity_action_amd.utils.synth import synth_state_dict
+        from aicity_action_amd.models.mvit import MViT as _M
         cores = min(os.cpu_count() or 1, 32)     # more threads than this slows the oracle down on a 256-core host
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        sd448 = {k: v.detach().cpu() for k, v in core.state_dict().items()} if args.crop == 448 else None
+        cfg224 = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"), ["NUM_GPUS", 0])
+        sd224 = synth_state_dict({k_: v_.shape for k_, v_ in _M(cfg224).state_dict().items()}, 0)
+        mv224 = copy.deepcopy(cfg224.MVIT.to_dict())
+        c224 = torch.randn(1, 3, 16, 224, 224)
+
+        def fwd_time(sd_, c_, mv_, n, threads):
+            torch.set_num_threads(threads)
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    O.forward(sd_, c_, mv_)
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts)[len(ts) // 2]
+        fwd_time(sd224, c224, mv224, 1, cores)                                  # warm-up
+        f224 = fwd_time(sd224, c224, mv224, 3, cores)                           # median of 3
+        f224_1t = fwd_time(sd224, c224, mv224, 1, 1)
+        f448 = fwd_time(sd448, clip[:1].cpu(), mv, 1, cores) if sd448 is not None else None
         torch.set_num_threads(cores)
-        sd = {k: v.detach().cpu() for k, v in core.state_dict().items()}
-        crop_cpu = args.crop
+        extra = {"forward_224_s_per_clip": round(f224, 4), "forward_224_1thread_s_per_clip": round(f224_1t, 4),
+                 "forward_448_s_per_clip": None if f448 is None else round(f448, 4), "cpu_model": cpu_model,
+                 "protocol": "1 warm-up + median of 3 @224, 1 timed @448, 1 timed 1-thread @224 (BASELINE.md section 4, bounded)"}
         if train:
             import psutil
-            if args.crop == 448 and psutil.virtual_memory().available < 96 * 2 ** 30:
-                crop_cpu = 224      # fp32 autograd of the unfused path keeps ~20 GB of score matrices per clip @448
-        if crop_cpu != args.crop:
-            ycpu = "MVITV2_FULL_B_16x4_CONV.yaml"
-            cfg_cpu = load_config(os.path.join(ROOT, "configs", "Aicity", ycpu), ["NUM_GPUS", 0])
-            from aicity_action_amd.utils.synth import synth_state_dict
-            from aicity_action_amd.models.mvit import MViT as _M
-            sd = synth_state_dict({k_: v_.shape for k_, v_ in _M(cfg_cpu).state_dict().items()}, 0)
-            mv_cpu = copy.deepcopy(cfg_cpu.MVIT.to_dict())
-            c1 = torch.randn(1, 3, 16, 224, 224)
-        else:
-            mv_cpu = mv
-            c1 = clip[:1].cpu()
-        n_timed = 1 if crop_cpu == 448 else 4
-        if train:
-            mv_cpu = dict(mv_cpu, DROPPATH_RATE=0.0)
+            big = args.crop == 448 and psutil.virtual_memory().available >= 96 * 2 ** 30   # ~20 GB of fp32 score matrices per clip
+            sd_t, c_t, mv_t, crop_cpu = (sd448, clip[:1].cpu(), mv, 448) if big else (sd224, c224, mv224, 224)
+            mv_t = dict(mv_t, DROPPATH_RATE=0.0)
             y1 = torch.zeros(1, cfg.MODEL.NUM_CLASSES)
             y1[0, 0] = 1.0
-            sdg = {k_: v_.clone().requires_grad_(True) for k_, v_ in sd.items()}
-
-            def cpu_step():
-                out, _ = O.forward(sdg, c1, mv_cpu, training=True)
-                O.soft_target_cross_entropy(out, y1).backward()
-            kind_txt = "forward+backward (torch autograd over the oracle)"
+            sdg = {k_: v_.clone().requires_grad_(True) for k_, v_ in sd_t.items()}
+            t0 = time.perf_counter()
+            out_c, _ = O.forward(sdg, c_t, mv_t, training=True)
+            O.soft_target_cross_entropy(out_c, y1).backward()
+            cdt = time.perf_counter() - t0
+            cpu = {"value": round(1.0 / cdt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                   "sample": "1 x forward+backward (torch autograd over the oracle) B=1 @%d fp32 after the forward warm-ups "
+                             "(oracle/mvit_oracle.py, torch CPU, %d threads)" % (crop_cpu, cores)}
         else:
-            def cpu_step():
-                with torch.no_grad():
-                    O.forward(sd, c1, mv_cpu)
-            kind_txt = "forward"
-        if crop_cpu != 448:
-            cpu_step()                                 # warm-up (skipped @448 to bound the sample)
-        t0 = time.perf_counter()
-        for _ in range(n_timed):
-            cpu_step()
-        cdt = time.perf_counter() - t0
-        cpu = {"value": round(n_timed / cdt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-               "sample": "%d x %s B=1 @%d fp32 (oracle/mvit_oracle.py, torch CPU, %d threads)" % (n_timed, kind_txt, crop_cpu, cores)}
+            val = f448 if f448 is not None else f224
+            cpu = {"value": round(1.0 / val, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                   "sample": "forward B=1 @%d fp32 (oracle/mvit_oracle.py, torch CPU, %d threads)" % (args.crop, cores)}
+        cpu.update(extra)
 
     if rank == 0:
         gf = GFLOP_PER_CLIP[args.crop] * (3.0 if train else 1.0)   # train step = 3x forward FLOPs
@@ -279,7 +381,9 @@ def main():
         line = {
             "metric": "clips/sec (node) MViTv2-B 16x4@%d %s" % (args.crop, args.mode),
             "value": round(clips_per_s, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_step_event_median": None if ev_ms is None else round(ev_ms, 4),
+            "timing": "wall clock over the K steps between barrier + synchronize (driver contract); event median = per-step hipEvent intervals",
+            "higher_is_better": True,
             "scaling": "strong" if args.mode == "window" else "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("MViTv2-B 16x4 crop=%d %s train step (fwd+bwd+clip+AdamW), synthetic clips, BS=%d per GPU (BASELINE configs[2]/[3])"
@@ -298,6 +402,12 @@ def main():
                                           "16 frames (stride 4), resize to %d, bf16 forward, batch %d (BASELINE configs[4])" % (args.crop, args.batch))
             line["config"]["parallelism"] = "dp%d (windows sharded rank-strided, all_gather of [n,18] scores)" % world
             line["seconds_per_30s_stream_3views"] = round(dt / args.steps, 4)
+            line["parity_note"] = ("front end (gather + 8-bit INTER_LINEAR resize + normalise) is bit-exact vs oracle/window_oracle.py; "
+                                   "cv2 is absent from this image, so that restatement of cv2.resize is itself unpinned (SURVEY 8f rank 1: parity unpinned)")
+        if args.mode == "loop":
+            line["config"]["workload"] += " driven by engine.train_epoch (reference loop order, LOG_PERIOD 10, no per-iteration host sync)"
+        if forward_rec is not None:
+            line["forward"] = forward_rec
         line.update(extra_rooflines)
         print(json.dumps(line))
     if world > 1:

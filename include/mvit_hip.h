@@ -9,7 +9,11 @@
  *
  * Conventions ("C-ABI layer"):
  *   - plain pointers + sizes; all pointers are DEVICE pointers owned by the caller;
- *   - the library never allocates, never synchronises, never throws;
+ *   - the library never allocates DEVICE MEMORY, never synchronises, never throws.  The one piece of state it owns is a
+ *     lazily created side stream + two events per device (mvit_side_stream / mvit_side_fork / mvit_side_join below, also used
+ *     inside mvit_attention_bwd): created on the first call that needs it, from the calling thread, with no lock -- the
+ *     threading contract of the reference applies (one process per GPU, the model touched by that process's main thread
+ *     only, slowfast/utils/misc.py:307-320); set MVIT_NO_SIDE_STREAM to keep every launch on the caller's stream;
  *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns
  *     0 (MVIT_OK) or a negative MVIT_E* code;
  *   - token-major activations: [batch][token][channel], channel contiguous;

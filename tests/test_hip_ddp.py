@@ -35,7 +35,8 @@ def _worker(rank, world, port, q):
     cfg.NUM_GPUS = 1
     model = build_model(cfg, gpu_id=0).train()
     load_synth_weights(model, 0)
-    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0)
+    from aicity_action_amd.models.build import wrap_ddp
+    model = wrap_ddp(model, cfg, 0)           # the wrap build_model applies for NUM_GPUS > 1 (bucket views, static graph)
     clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
     labels = torch.from_numpy(z["train.labels"]).cuda()
     n = meta["batch"] // world
@@ -103,7 +104,9 @@ def _rccl_worker(port, q):
         load_synth_weights(model, 0)
         core = model
         if tag == "ddp":
-            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0)
+            from aicity_action_amd.models.build import wrap_ddp
+            cfg.HIP.DDP_BF16_GRADS = False
+            model = wrap_ddp(model, cfg, 0)
         opt = construct_optimizer(model, cfg)
         clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
         labels = torch.from_numpy(z["train.labels"]).cuda()
@@ -145,3 +148,73 @@ def test_ddp_rccl_single_rank_matches_plain_training():
     print("RCCL DDP (1 rank) vs plain, 3 steps: losses", l1, "parameter difference worst %.2e mean %.2e" % (worst, mean))
     assert worst <= 3 * 1e-3 * 1.01
     assert mean <= 1e-5
+
+
+def test_bench_script_two_ranks_gloo_on_one_gpu():
+    """The exact script the driver launches for the scaling curve (`python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N --steps K --warmup W`), here with two ranks sharing this box's one GPU over gloo (RCCL refuses two ranks on one
+    device): rendezvous, DDP wrap from build_model, barrier / max-over-ranks timing and the ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MVIT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-kernel-timing", "--no-forward-record"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["value"] > 0 and abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-2 * d["value"]
+    assert d["config"]["parallelism"].startswith("dp2")
+
+
+def test_ddp_bf16_gradient_payload_hook():
+    """HIP.DDP_BF16_GRADS: the all-reduce payload is compressed to bf16 (70.6 MB instead of 141 MB per step) and decompressed into
+    the fp32 gradients; on one rank the result is the gradient rounded through bf16."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_bf16_hook_worker, args=(_free_port(), q))
+    p.start()
+    worst = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    print("bf16 gradient payload vs fp32 gradients: worst relative difference %.2e" % worst)
+    assert 0.0 < worst <= 2.0 ** -8
+
+
+def _bf16_hook_worker(port, q):
+    import torch.distributed as dist
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.models.build import wrap_ddp
+    from aicity_action_amd.solver import soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    z, meta = load_golden("tiny_even")
+    grads = []
+    for bf16 in (False, True):
+        cfg = cfg_for_case(meta, "fp32", train=True)
+        cfg.NUM_GPUS = 1
+        cfg.HIP.DDP_BF16_GRADS = bf16
+        model = build_model(cfg, gpu_id=0).train()
+        load_synth_weights(model, 0)
+        model = wrap_ddp(model, cfg, 0)
+        clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+        labels = torch.from_numpy(z["train.labels"]).cuda()
+        soft_target_cross_entropy(model([clip]), labels).backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in model.module.named_parameters()})
+    worst = 0.0
+    for k in grads[0]:
+        ref = grads[0][k]
+        worst = max(worst, ((grads[1][k] - ref).abs().max() / ref.abs().max().clamp_min(1e-20)).item())
+    q.put(worst)
+    dist.barrier()
+    dist.destroy_process_group()
