@@ -310,68 +310,103 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass B (bf16 MFMA): dK, dV.   grid (ceil(Lk/128), B*heads), 4 waves x 32 keys; streams 64-query tiles.
+// pass B (bf16 MFMA): dK, dV.   grid (ceil(Lk/128), B*heads[, splits]), 4 waves x 32 keys; streams 64-query tiles.
 // ------------------------------------------------------------------------------------------------
-// SPLIT: gridDim.z workgroups share one key block, each sweeping a slice of the queries and adding its partial dK/dV into
-// fp32 buffers (dKf/dVf, zeroed by the launcher) -- used when B*heads*ceil(Lk/128) alone cannot fill the chip (block 0).
+// Same data movement as pass A: the 64-query tiles of Q and dO (one rotation image each, serving the row reads of
+// S = Q K^T / dP = dO V^T AND the transposing reads of dV^T += dO^T P / dK^T += Q^T dS) and the tile's lse / delta rows arrive
+// through a 3-stage LDS ring filled by global_load_lds (two tiles in flight, one s_barrier per tile, counted vmcnt); nothing
+// is staged through registers and nothing is written to LDS by the waves themselves.  (The first version wrote two images
+// per operand with ds_write_b128 behind two barriers per tile: the LDS write path alone was ~40 % busy.)
+// SPLIT: gridDim.z workgroups share one key block, each sweeping a slice of the query tiles and writing its partial dK / dV
+// as an fp32 slab dKf/dVf[z] (plain stores); attn_bwd_dkv_reduce_kernel sums the slabs in z order -- deterministic, no atomics.
+#define BK_STAGES 3
+#define BK_IMG (B_T * B_ROWB)               // 12 KiB: one 64 x 96 rotation image
+#define BK_STAGEB (2 * BK_IMG + 1024)       // Q image | dO image | lse[64] | delta[64] | 2 x 256 B landing pads
+#define BK_LDS (BK_STAGES * BK_STAGEB)      // 75 KiB: two workgroups per CU
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
-                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
-                                                           float* __restrict__ dKf, float* __restrict__ dVf, int heads,
-                                                           int Lq, int Lk, float scale, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * B_T * B_ROWB + 2 * B_T * 4];
-    char* sQ = smem;                        // rotation image (row reads)
-    char* sQp = smem + B_T * B_ROWB;        // plain image (transposed reads)
-    char* sD = smem + 2 * B_T * B_ROWB;     // dO rotation image
-    char* sDp = smem + 3 * B_T * B_ROWB;    // dO plain image
-    float* sL = reinterpret_cast<float*>(smem + 4 * B_T * B_ROWB);   // lse[64], delta[64]
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
+                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                              const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
+                                                              float* __restrict__ dKf, float* __restrict__ dVf, int heads,
+                                                              int Lq, int Lk, float scale, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // BK_STAGES x BK_STAGEB
     int ktile, bh;
     xcd_group_map(ktile, bh);
     const int b = bh / heads, g = bh - b * heads;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     int ki = ktile * 128 + wave * 32 + r;
     const bool k_ok = ki < Lk;
     ki = k_ok ? ki : Lk - 1;
     const int C = heads * 96;
-    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
-    const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
-    const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
-    const bf16_t* dOb = dO + (int64_t)b * Lq * C + g * 96;
-    bf16x8 kf[6], vf[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)ki * 96 + 16 * ks + 8 * h);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)ki * 96 + 16 * ks + 8 * h);
-    }
-    int s_row[3], s_chk[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = tid + 256 * i;
-        s_row[i] = c / 12;
-        s_chk[i] = c - s_row[i] * 12;
-    }
-    uint4 rq[3], rd[3];
-    float rl = 0.f;
-    auto gload = [&](int q0) {
+    const char* Qb = reinterpret_cast<const char*>(Q + (int64_t)bh * Lq * 96);
+    const char* dOb = reinterpret_cast<const char*>(dO + (int64_t)b * Lq * C + g * 96);
+    const float* Lb = LSE + (int64_t)bh * Lq;
+    const float* Db = delta + (int64_t)bh * Lq;
+
+    const int64_t do_ld = (int64_t)C * 2;       // bytes between consecutive dO rows
+    const int nqt_all = (Lq + B_T - 1) / B_T;
+    const int per_z = (nqt_all + gridDim.z - 1) / gridDim.z;
+    const int qt_beg = SPLIT ? blockIdx.z * per_z : 0;
+    const int qt_end = SPLIT ? (qt_beg + per_z < nqt_all ? qt_beg + per_z : nqt_all) : nqt_all;
+    // DMA pieces (3 per wave and image): LDS position p = 64*piece + lane holds chunk (p%12 - rot(row)) of row p/12.  The piece
+    // geometry is recomputed at every call from the lane id (a dozen VALU ops): kept live across the loop it costs six registers
+    // the accumulators need
+    // The DMA is inline asm (SGPR base + 32-bit lane offset, LDS base in M0): the compiler then does not know that LDS is written
+    // asynchronously, so its own LDS reads (row reads and ds_read_b64_tr_b16 builtins, register-coalesced and scheduled by it)
+    // carry no vmcnt(0); ordering is the counted s_waitcnt vmcnt + s_barrier at the top of every tile.
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma16 = [&](const char* base, uint32_t off, uint32_t lds) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(off), "s"(base) : "memory");
+    };
+    auto dma4 = [&](const char* base, uint32_t off, uint32_t lds) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds), "v"(off), "s"(base) : "memory");
+    };
+    auto dma = [&](int qt, int stage) {
+        const int q0 = qt * B_T;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_a + stage * BK_STAGEB + 1024 * (3 * wave));
+        const int last = Lq - 1 - q0;            // rows past Lq re-read the last valid row (finite; their P is masked to 0 below)
+        const char* qbase = Qb + (int64_t)q0 * B_ROWB;           // wave-uniform tile bases
+        const char* dbase = dOb + (int64_t)q0 * do_ld;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));             // piece geometry recomputed per call (a dozen VALU ops) instead of living in registers
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int q = q0 + s_row[i];
-            rq[i] = make_uint4(0, 0, 0, 0);
-            rd[i] = rq[i];
-            if (q < Lq) {
-                rq[i] = *reinterpret_cast<const uint4*>(Qb + (int64_t)q * 96 + 8 * s_chk[i]);
-                rd[i] = *reinterpret_cast<const uint4*>(dOb + (int64_t)q * C + 8 * s_chk[i]);
-            }
+            const int p = 64 * (3 * wave + i) + ln;
+            int row = p / 12;
+            const int pos = p - row * 12;
+            int c = pos - ((row >> 2) & 3);
+            c = c < 0 ? c + 12 : c;
+            row = row < last ? row : last;
+            dma16(qbase, (uint32_t)(row * 12 + c) * 16u, dst + 1024 * i);
+            dma16(dbase, (uint32_t)row * (uint32_t)do_ld + (uint32_t)c * 16u, dst + BK_IMG + 1024 * i);
         }
-        if (tid < 128) {
-            const int q = q0 + (tid & 63);
-            // invalid queries: lse = +inf -> P = exp2(-inf) = 0
-            rl = q < Lq ? (tid < 64 ? LSE[(int64_t)bh * Lq + q] : delta[(int64_t)bh * Lq + q]) : (tid < 64 ? INFINITY : 0.f);
-        }
+        // lse (even waves) / delta (odd waves) of the tile's 64 queries: 4 bytes per lane; waves 2, 3 land in the pads so that
+        // every wave issues the same number of DMA instructions per tile (one vmcnt count for all)
+        const int ql = ln < last ? ln : last;
+        dma4(reinterpret_cast<const char*>(((wave & 1) ? Db : Lb) + q0), (uint32_t)ql * 4u,
+             __builtin_amdgcn_readfirstlane(smem_a + stage * BK_STAGEB + 2 * BK_IMG + 256 * wave));
     };
+    if (qt_beg < qt_end) dma(qt_beg, 0);
+    if (qt_beg + 1 < qt_end) dma(qt_beg + 1, 1);
+
+    // The K fragments of the wave's 32 keys stay in registers; the V fragments live in LDS (lane-linear, conflict-free 16-byte
+    // reads): with both in registers next to the 96 accumulator registers of dK^T / dV^T the compiler spilled a fragment set to
+    // scratch and its reloads' vmcnt(0) drained the DMA ring every block
+    bf16x8 kf[6], vf[6];
+    {
+        const bf16_t* Kb = Kt + (int64_t)bh * Lk * 96;
+        const bf16_t* Vb = V + (int64_t)bh * Lk * 96;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(Kb + (int64_t)ki * 96 + 16 * ks + 8 * h);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)ki * 96 + 16 * ks + 8 * h);
+        }
+        // consume the register operands once: their vmcnt wait is paid here, not inside the loop
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    }
     int roff[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
@@ -379,8 +414,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         p = p >= 12 ? p - 12 : p;
         roff[ks] = p * 16;
     }
+    // transposing reads on the rotation image: row 16*s16 + 4h + (i16>>2) (+8 for the second half), rotation h (+2)
     const int i16 = lane & 15, gi = lane >> 4;
-    const int t_lane = (4 * h + (i16 >> 2)) * B_ROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;
+    // (chunk position = (4 db + cl + rot) mod 12 with cl, rot <= 3: only db = 2 can wrap, so db = 0 / 1 share one lane address)
+    const int cl = 2 * (gi & 1) + ((i16 & 3) >> 1);
+    const int rl = cl + h, rh = cl + ((h + 2) & 3);
+    const int t_lo0 = (4 * h + (i16 >> 2)) * B_ROWB + 16 * rl + 8 * (i16 & 1);
+    const int t_hi0 = (4 * h + (i16 >> 2) + 8) * B_ROWB + 16 * rh + 8 * (i16 & 1);
+    const int t_lo2 = (4 * h + (i16 >> 2)) * B_ROWB + 16 * (8 + rl >= 12 ? rl - 4 : 8 + rl) + 8 * (i16 & 1);
+    const int t_hi2 = (4 * h + (i16 >> 2) + 8) * B_ROWB + 16 * (8 + rh >= 12 ? rh - 4 : 8 + rh) + 8 * (i16 & 1);
+    auto trf = [&](const char* img, int s16, int db) {      // one transposed 8-element fragment: two 4x16 transposing reads
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(img + s16 * 16 * B_ROWB + (db == 2 ? t_lo2 : t_lo0 + 64 * db)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(img + s16 * 16 * B_ROWB + (db == 2 ? t_hi2 : t_hi0 + 64 * db)));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
 
     f32x16 dk[3], dv[3];
 #pragma unroll
@@ -388,28 +435,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
-    const int nqt_all = (Lq + B_T - 1) / B_T;
-    const int per_z = (nqt_all + gridDim.z - 1) / gridDim.z;
-    const int qt_beg = SPLIT ? blockIdx.z * per_z : 0;
-    const int nqt = SPLIT ? (qt_beg + per_z < nqt_all ? qt_beg + per_z : nqt_all) : nqt_all;
-    gload(qt_beg * B_T);
-    for (int qt = qt_beg; qt < nqt; ++qt) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<uint4*>(sQ + rot_off(s_row[i], s_chk[i])) = rq[i];
-            *reinterpret_cast<uint4*>(sQp + s_row[i] * B_ROWB + s_chk[i] * 16) = rq[i];
-            *reinterpret_cast<uint4*>(sD + rot_off(s_row[i], s_chk[i])) = rd[i];
-            *reinterpret_cast<uint4*>(sDp + s_row[i] * B_ROWB + s_chk[i] * 16) = rd[i];
+    int stage = 0;
+    for (int qt = qt_beg; qt < qt_end; ++qt) {
+        if (qt + 1 < qt_end) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // 7 DMA instructions per wave and tile: this
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // tile has landed, the next may be in flight
+        __builtin_amdgcn_s_barrier();                                              // ... for every wave; stage-1's readers are done
+        if (qt + 2 < qt_end) dma(qt + 2, stage == 0 ? 2 : stage - 1);
+        const char* sQ = smem + stage * BK_STAGEB;
+        const char* sD = sQ + BK_IMG;
+        const float* sL = reinterpret_cast<const float*>(sQ + 2 * BK_IMG);      // lse[64] | delta[64]
+        if ((qt + 1) * B_T > Lq) {
+            // last, partial tile: its invalid rows were filled from the last valid query (finite data); their lse is set to +inf
+            // here, so P = exp2(-inf) = 0 and dS = 0 * finite = 0 -- no masked variant of the block code (a second copy of it in
+            // the loop cost 80 registers)
+            if (tid < 64 && qt * B_T + tid >= Lq) const_cast<float*>(sL)[tid] = INFINITY;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-        if (tid < 128) sL[tid] = rl;
-        __syncthreads();
-        if (qt + 1 < nqt) gload((qt + 1) * B_T);
-        // per 32-query block (keeps one S / dP accumulator pair live: the kernel fits 2 waves per SIMD):
+        stage = stage == BK_STAGES - 1 ? 0 : stage + 1;
+        // per 32-query block (one S / dP accumulator pair live: the kernel fits 2 waves per SIMD):
         //   S = Q . K^T and dP = dO . V^T (rows = queries in registers, column = this lane's key), P / dS in registers,
         //   then dV^T += dO^T . P and dK^T += Q^T . dS for the block's two 16-query k-steps
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        auto block = [&](auto qb_tag) {
+            constexpr int qb = decltype(qb_tag)::value;
             f32x16 s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -437,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 8 * sh + 4 * g4 + e;
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[i], scale_log2e, -ls[e]));
+                        float p = __builtin_amdgcn_exp2f(fmaf(s[i], scale_log2e, -ls[e]));
                         pv[4 * g4 + e] = p;
                         dsv[4 * g4 + e] = p * (dp[i] - ds4[e]);
                     }
@@ -449,24 +497,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
             for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
                 for (int db = 0; db < 3; ++db) {
-                    const bf16x8 dof = tr_frag(sDp + t_lane + (2 * qb + sh) * 16 * B_ROWB + db * 64);
-                    const bf16x8 qtf = tr_frag(sQp + t_lane + (2 * qb + sh) * 16 * B_ROWB + db * 64);
-                    dv[db] = mfma16(dof, pf[sh], dv[db]);
-                    dk[db] = mfma16(qtf, dsf[sh], dk[db]);
+                    dv[db] = mfma16(trf(sD, 2 * qb + sh, db), pf[sh], dv[db]);
+                    dk[db] = mfma16(trf(sQ, 2 * qb + sh, db), dsf[sh], dk[db]);
                 }
-        }
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
     }
     if (SPLIT) {
         if (k_ok) {
-            float* krow = dKf + ((int64_t)bh * Lk + ki) * 96;
-            float* vrow = dVf + ((int64_t)bh * Lk + ki) * 96;
+            const int64_t nkv = (int64_t)gridDim.y * Lk * 96;
+            float* krow = dKf + (int64_t)blockIdx.z * nkv + ((int64_t)bh * Lk + ki) * 96;
+            float* vrow = dVf + (int64_t)blockIdx.z * nkv + ((int64_t)bh * Lk + ki) * 96;
 #pragma unroll
             for (int db = 0; db < 3; ++db)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int d = 32 * db + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    atomicAdd(krow + d, dk[db][i] * scale);
-                    atomicAdd(vrow + d, dv[db][i]);
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int d = 32 * db + 8 * i4 + 4 * h;
+                    store4(krow + d, make_float4(dk[db][4 * i4] * scale, dk[db][4 * i4 + 1] * scale, dk[db][4 * i4 + 2] * scale,
+                                                 dk[db][4 * i4 + 3] * scale));
+                    store4(vrow + d, make_float4(dv[db][4 * i4], dv[db][4 * i4 + 1], dv[db][4 * i4 + 2], dv[db][4 * i4 + 3]));
                 }
         }
         return;
@@ -483,6 +533,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                              dk[db][4 * i4 + 3] * scale));
                 store4(vrow + d, make_float4(dv[db][4 * i4], dv[db][4 * i4 + 1], dv[db][4 * i4 + 2], dv[db][4 * i4 + 3]));
             }
+    }
+}
+
+// dK / dV = sum over the nz query-slice slabs, in z order (fixed summation order: bit-reproducible), cast to the 16-bit type
+__global__ __launch_bounds__(256) void attn_bwd_dkv_reduce_kernel(const float* __restrict__ dKf, const float* __restrict__ dVf,
+                                                                  bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int64_t n4,
+                                                                  int nz) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = load4(dKf + 4 * i), c = load4(dVf + 4 * i);
+        for (int z = 1; z < nz; ++z) {
+            const float4 a2 = load4(dKf + 4 * (i + z * n4)), c2 = load4(dVf + 4 * (i + z * n4));
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+            c.x += c2.x; c.y += c2.y; c.z += c2.z; c.w += c2.w;
+        }
+        store4(dK + 4 * i, a);
+        store4(dV + 4 * i, c);
     }
 }
 
@@ -620,14 +686,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void cast2_bf16_kernel(const float* __restrict__ a, bf16_t* __restrict__ oa, const float* __restrict__ b,
-                                                         bf16_t* __restrict__ ob, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        store4(oa + 4 * i, load4(a + 4 * i));
-        store4(ob + 4 * i, load4(b + 4 * i));
-    }
-}
-
 static int dkv_splits(int B, int heads, int Lq, int Lk) {
     const int64_t base = (int64_t)B * heads * ((Lk + 127) / 128);
     if (base >= 384) return 1;
@@ -637,12 +695,18 @@ static int dkv_splits(int B, int heads, int Lq, int Lk) {
     return (int)(z < 1 ? 1 : z);
 }
 
-// delta [B*heads*Lq] + (split path) fp32 dK, dV partial sums [2][B*heads*Lk*96]
+// delta [B*heads*Lq] + (split path) fp32 dK, dV partial slabs [2][splits][B*heads*Lk*96]
 extern "C" int64_t mvit_attention_bwd_workspace_bytes2(int B, int heads, int Lq, int Lk) {
-    return ((int64_t)B * heads * Lq + 2ll * B * heads * Lk * 96) * (int64_t)sizeof(float);
+    const int nz = dkv_splits(B, heads, Lq, Lk);
+    return ((int64_t)B * heads * Lq + (nz > 1 ? 2ll * nz : 0ll) * B * heads * Lk * 96) * (int64_t)sizeof(float);
 }
-extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq) {
-    return mvit_attention_bwd_workspace_bytes2(B, heads, Lq, 6272);
+extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq) {      // upper bound over Lk <= Lq*16 (older callers)
+    int64_t best = 0;
+    for (int Lk = 64; Lk <= 16384; Lk *= 2) {
+        const int64_t v = mvit_attention_bwd_workspace_bytes2(B, heads, Lq, Lk);
+        best = v > best ? v : best;
+    }
+    return best;
 }
 
 // q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.
@@ -682,23 +746,29 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
         MVIT_LAUNCH_CHECK();
+        static bool dkv_attr_done = false;
+        if (!dkv_attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess)
+                return MVIT_ELAUNCH;
+            dkv_attr_done = true;
+        }
         const int nz = dkv_splits(B, heads, Lq, Lk);
         if (nz > 1) {
             float* dkf = workspace + rows;
             const int64_t nkv = (int64_t)B * heads * Lk * 96;
-            float* dvf = dkf + nkv;
-            if (hipMemsetAsync(dkf, 0, 2 * nkv * sizeof(float), skv) != hipSuccess) return MVIT_ELAUNCH;
+            float* dvf = dkf + (int64_t)nz * nkv;
             dim3 gk((Lk + 127) / 128, B * heads, nz);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), 0, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), BK_LDS, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                                (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale, sl2);
             MVIT_LAUNCH_CHECK();
             int64_t cb = (nkv / 4 + 255) / 256;
             if (cb > 4096) cb = 4096;
-            hipLaunchKernelGGL(cast2_bf16_kernel, dim3((unsigned)cb), dim3(256), 0, skv, dkf, (bf16_t*)dk, dvf, (bf16_t*)dv, nkv / 4);
+            hipLaunchKernelGGL(attn_bwd_dkv_reduce_kernel, dim3((unsigned)cb), dim3(256), 0, skv, dkf, dvf, (bf16_t*)dk, (bf16_t*)dv, nkv / 4, nz);
             MVIT_LAUNCH_CHECK();
         } else {
             dim3 gk((Lk + 127) / 128, B * heads);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), 0, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), BK_LDS, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                                (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale, sl2);
             MVIT_LAUNCH_CHECK();
         }

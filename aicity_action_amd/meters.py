@@ -10,8 +10,8 @@ tests/golden/train_loop.json pins byte for byte.  The internals are different:
   plus sample-weighted running sums -- no per-series deque objects;
 * per-iteration scalars that live on the device go through ``DeviceScalarQueue``: each iteration issues ONE non-blocking
   device-to-pinned-host copy of the stacked scalars and an event; the host absorbs a row when its event has completed, i.e.
-  normally one iteration late, and blocks only when a log line (every ``LOG_PERIOD`` iterations) or the end of the epoch needs
-  the numbers, or when it is ``depth`` iterations ahead of the GPU.  The reference's ``.item()`` x3 per iteration
+  normally one iteration late, and blocks only at the end of the epoch or when it is ``depth`` iterations ahead of the GPU; a
+  ``LOG_PERIOD`` line whose last row is still in flight is emitted (unchanged) the moment that row lands.  The reference's ``.item()`` x3 per iteration
   (train_net.py:290-294) is a full pipeline drain per step;
 * ``TestMeter`` accumulates a whole batch of clip scores with one ``index_add_`` / ``scatter_reduce_`` instead of a Python loop
   per clip.
@@ -177,10 +177,6 @@ class _IterClock(object):
         return (self._t_end if self._t_end is not None else time.perf_counter()) - self._t_data_end
 
 
-class _NanLoss(RuntimeError):
-    pass
-
-
 def _check_nan(loss):
     if math.isnan(loss):
         raise RuntimeError("ERROR: Got NaN losses {}".format(datetime.datetime.now()))
@@ -202,38 +198,46 @@ class TrainMeter(_IterClock):
         self._single = not cfg.DATA.MULTI_LABEL
         self._win = _Window(cfg.LOG_PERIOD, 3)
         self._queue = DeviceScalarQueue(3, depth=int(getattr(getattr(cfg, "HIP", None), "STAT_QUEUE_DEPTH", 2) or 2))
+        self._fed = 0                                # rows handed in (absorbed or still in flight)
+        self._due = []                               # log lines waiting for their last row: (rows needed, epoch, iter)
         self.lr = None
 
     def reset(self):
-        self._queue.ready(wait=True)
+        self._absorb(wait=True)
         self._win.clear()
+        self._fed, self._due = 0, []
         self.lr = None
 
     # -- feeding -------------------------------------------------------------------------------------------------------
     def update_stats(self, top1_err, top5_err, loss, lr, mb_size):
         """Host floats (the reference's signature)."""
-        _check_nan(loss)
-        self.lr = lr
-        self._win.push([loss, top1_err if self._single else 0.0, top5_err if self._single else 0.0], mb_size)
+        self._fed += 1
+        self._push(top1_err, top5_err, loss, lr, mb_size)
 
     def update_stats_async(self, stats_dev, lr, mb_size):
         """``stats_dev`` = device tensor ``[loss, top1_err, top5_err]``: queued, absorbed when its copy has landed."""
+        self._fed += 1
         self._queue.put(stats_dev, (lr, mb_size))
         self._absorb(wait=False)
 
+    def _push(self, top1_err, top5_err, loss, lr, mb_size):
+        _check_nan(loss)
+        self.lr = lr
+        self._win.push([loss, top1_err if self._single else 0.0, top5_err if self._single else 0.0], mb_size)
+        while self._due and self._due[0][0] == self._win.n:      # a log line was waiting for exactly this row
+            _, ep, it = self._due.pop(0)
+            self._emit_iter(ep, it)
+
     def _absorb(self, wait):
         for row, (lr, mb) in self._queue.ready(wait):
-            self.update_stats(float(row[_TOP1]), float(row[_TOP5]), float(row[_LOSS]), lr, mb)
+            self._push(float(row[_TOP1]), float(row[_TOP5]), float(row[_LOSS]), lr, mb)
 
     # -- reporting -----------------------------------------------------------------------------------------------------
     @property
     def num_samples(self):
         return self._win.weight
 
-    def log_iter_stats(self, cur_epoch, cur_iter):
-        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
-            return None
-        self._absorb(wait=True)
+    def _emit_iter(self, cur_epoch, cur_iter):
         gpu, _ = _mem_fields()
         stats = {"_type": "train_iter", "epoch": "{}/{}".format(cur_epoch + 1, self._cfg.SOLVER.MAX_EPOCH),
                  "iter": "{}/{}".format(cur_iter + 1, self.epoch_iters), "loss": self._win.median(_LOSS), "lr": self.lr,
@@ -242,6 +246,17 @@ class TrainMeter(_IterClock):
             stats["top1_err"] = self._win.median(_TOP1)
             stats["top5_err"] = self._win.median(_TOP5)
         return _log(stats)
+
+    def log_iter_stats(self, cur_epoch, cur_iter):
+        """The ``train_iter`` line of every ``LOG_PERIOD``-th iteration.  Returns the line when all its rows are on the host
+        already; otherwise None, and the (identical) line is logged as soon as the iteration's scalars arrive."""
+        if (cur_iter + 1) % self._cfg.LOG_PERIOD != 0:
+            return None
+        self._absorb(wait=False)
+        if self._win.n >= self._fed:
+            return self._emit_iter(cur_epoch, cur_iter)
+        self._due.append((self._fed, cur_epoch, cur_iter))
+        return None
 
     def log_epoch_stats(self, cur_epoch):
         self._absorb(wait=True)

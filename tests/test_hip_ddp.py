@@ -212,9 +212,12 @@ def _bf16_hook_worker(port, q):
         torch.cuda.synchronize()
         grads.append({k: p.grad.detach().clone() for k, p in model.module.named_parameters()})
     worst = 0.0
+    gmax = max(g.abs().max().item() for g in grads[0].values())
     for k in grads[0]:
         ref = grads[0][k]
-        worst = max(worst, ((grads[1][k] - ref).abs().max() / ref.abs().max().clamp_min(1e-20)).item())
+        if ref.abs().max().item() < 1e-4 * gmax:      # analytically-zero gradients (k bias: softmax shift invariance) are rounding noise
+            continue
+        worst = max(worst, ((grads[1][k] - ref).abs().max() / ref.abs().max()).item())
     q.put(worst)
     dist.barrier()
     dist.destroy_process_group()

@@ -76,6 +76,24 @@ def main():
                                             _hip.BF16, st))
             t = lse.view(B * h, Lq)[:, :(Lq // 128) * 128].reshape(B * h, Lq // 128, 4, 32)[..., :8].float()
             print("phase cycles/tile (wait, barrier+dma, S+max, softmax, PV issue, -):", [round(x, 1) for x in t.mean(dim=(0, 1, 2)).tolist()], "sum", round(t.mean(dim=(0, 1, 2)).sum().item(), 1))
+    elif op == "attnbwd":
+        B, h, Lq, Lk = (int(v) for v in a[:4])
+        reps = int(a[4]) if len(a) > 4 else 10
+        q = torch.randn(B, h, Lq, 96, device=dev).bfloat16()
+        k = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
+        v = torch.randn(B, h, Lk, 96, device=dev).bfloat16()
+        do = torch.randn(B, Lq, h * 96, device=dev).bfloat16()
+        o = torch.empty(B, Lq, h * 96, device=dev, dtype=torch.bfloat16)
+        lse = torch.empty(B, h, Lq, device=dev)
+        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5, 1, _hip.BF16, st))
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(L.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk) // 4, device=dev)
+
+        def fn():
+            _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(do), _hip.ptr(dq),
+                                            _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, 1, _hip.BF16, st))
+        ms = timeit(fn, reps)
+        print("attnbwd B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s credited (2x forward)" % (B, h, Lq, Lk, ms * 1e3, 8.0 * B * h * Lq * Lk * 96 / ms / 1e9))
     elif op == "stem":
         B = int(a[0]); reps = int(a[1]) if len(a) > 1 else 20
         clip = torch.randn(B, 3, 16, 448, 448, device=dev)
