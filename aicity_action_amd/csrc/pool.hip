@@ -870,9 +870,16 @@ static int launch_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
+int mvit_internal_pool_march_dgrad1(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                    int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
                                    int H, int W, int act_dtype, hipStream_t st) {
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
+    static const int march_env = getenv("MVIT_POOL_MARCH") ? atoi(getenv("MVIT_POOL_MARCH")) : -1;
+    if (march_env >= 0 ? march_env != 0 : W <= 56) {
+        const int rc = mvit_internal_pool_march_dgrad1(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);
+        if (rc != MVIT_EUNSUPPORTED) return rc;
+    }
     return act_dtype == MVIT_BF16 ? launch_pool_dgrad_tiled<bf16_t>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, st)
                                   : launch_pool_dgrad_tiled<float>(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, st);
 }
@@ -908,6 +915,12 @@ int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, c
     return rc < 0 ? rc : rows;
 }
 
+int mvit_internal_pool_march_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const float* beta, void* out,
+                                 void* xhat, float* rstd, int B, int heads, int T, int H, int W, int stride_hw, float eps, int act_dtype,
+                                 hipStream_t st);      // pool_march.hip
+int mvit_internal_pool_march_dgrad1(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
+                                    int H, int W, int act_dtype, hipStream_t st);
+
 // Training forward: additionally keeps xhat = (conv - mean) * rstd ([B][heads][T*Ho*Wo][96], act-typed) and rstd (fp32 per token),
 // which is all the LayerNorm backward needs -- the backward then skips the second convolution (mvit_pool_conv_ln_bwd_saved).
 extern "C" int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
@@ -924,6 +937,16 @@ extern "C" int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan
     if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (stride_hw == 1 || stride_hw == 2) {
+        // pool_march.hip (7 x 7 tiles, in-register LayerNorm) where it measured faster than the 8-wide tiles below: stride 1 on
+        // the <= 56 x 56 grids (56: 93 vs 99 us, 14: 31 vs 34 us, 28: tie; 112 x 112 and stride 2: 8-wide tiles 5-15 % faster --
+        // both forms are fp32-VALU-bound).  MVIT_POOL_MARCH=0 / 1 forces one form (A/B).
+        static const int march_env = getenv("MVIT_POOL_MARCH") ? atoi(getenv("MVIT_POOL_MARCH")) : -1;
+        const bool march = march_env >= 0 ? march_env != 0 : (stride_hw == 1 && W <= 56);
+        if (march) {
+            const int rc = mvit_internal_pool_march_fwd(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, stride_hw, eps,
+                                                        act_dtype, st);
+            if (rc != MVIT_EUNSUPPORTED) return rc;
+        }
         if (act_dtype == MVIT_BF16) {
             if (stride_hw == 1) return launch_pool_tiled<bf16_t, 1>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
             return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, st);
