@@ -56,6 +56,8 @@ _SIGS = {
     "mvit_linear_gelu_fwd_dsave": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_dact_fwd": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_wgrad": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    "mvit_linear_wgrad_workspace_bytes": (c_l, [c_i, c_l, c_i, c_l, c_i, c_l, c_i, c_i, c_i]),
+    "mvit_linear_wgrad2": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
     "mvit_colsum_workspace_bytes": (c_l, [c_i]),
     "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),
     "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i]),
@@ -71,6 +73,8 @@ _SIGS = {
     "mvit_maxpool_skip_bwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_stem_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
+    "mvit_stem_bwd3": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),
     "mvit_head_ln_partial": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mvit_head_project_train": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -81,18 +81,23 @@ class _Ctx(object):
         waves of workgroups; ``join_side()`` at the end of the block's backward makes the results visible to the caller's stream."""
         adt = _hip.F32 if a.dtype == torch.float32 else _hip.BF16
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
+        M = a.shape[0]
+
+        def launch():
+            # deterministic form: per-chunk partial slabs in a workspace, added in chunk order (no float atomics)
+            dW, db = self.zeros(N, K), self.zeros(N)
+            nb = self.L.mvit_linear_wgrad_workspace_bytes(adt, K, ddt, N, 1 if row_scale is not None else 0, M, N, K, self.act)
+            ws = _ws(nb, a.device) if nb > 0 else None
+            _hip.check(self.L.mvit_linear_wgrad2(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
+                                                 _hip.ptr(db), M, N, K, self.act, _hip.ptr(ws), nb, _st()), "wgrad")
+            return dW, db
         side = self._side()
         if side is None:
-            dW, db = self.zeros(N, K), self.zeros(N)
-            _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
-                                                _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
-            return dW, db
+            return launch()
         cur = torch.cuda.current_stream(a.device)
         side.wait_stream(cur)                       # the operands were produced on the caller's stream
         with torch.cuda.stream(side):
-            dW, db = self.zeros(N, K), self.zeros(N)
-            _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
-                                                _hip.ptr(db), a.shape[0], N, K, self.act, _st()), "wgrad")
+            dW, db = launch()
         for t in (a, dy, row_scale):
             if t is not None:
                 t.record_stream(side)               # keep the operands' memory until the side stream is done with it
@@ -195,8 +200,10 @@ class _StemFn(torch.autograd.Function):
         dW = hx.zeros(96, 3, 3, 7, 7)
         dps = hx.zeros(*m.pos_embed_spatial.shape)
         dpt = hx.zeros(*m.pos_embed_temporal.shape)
-        _hip.check(hx.L.mvit_stem_bwd2(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act, _st()),
-                   "stem_bwd")
+        nb = hx.L.mvit_stem_bwd_workspace_bytes(B, T, S, hx.act)        # slab form: ordered sums, no float atomics
+        ws = _ws(nb, dev)
+        _hip.check(hx.L.mvit_stem_bwd3(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act,
+                                       _hip.ptr(ws), nb, _st()), "stem_bwd")
         db = hx.colsum(dx.view(-1, 96))
         return None, dW, db, dps, dpt, None
 

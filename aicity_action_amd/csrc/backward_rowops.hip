@@ -99,41 +99,85 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out[j] (+)= sum_b part[b][j]   -- block = 64 columns x 4 part-slices, LDS combine; blockIdx.y slices the partial rows and
-// the slices meet in fp32 atomics (outputs pre-zeroed by the launcher unless accumulating).
+// out[j] (+)= sum_b part[b][j]: deterministic column sums of a [nparts][width] partial table in ONE launch, no float atomics.
+// grid = (64-column blocks, row slices).  Every workgroup sums its slice of the rows (4 interleaved row groups, fixed order)
+// and, when there is more than one slice, parks the result in a per-launch scratch row; the slice that ARRIVES LAST for a
+// column block (agent-scope release + ticket, acquire on the last arriver: cdna guide G16 counter form) adds the parked rows
+// in slice order -- so the summation order is a function of the launch geometry only, never of timing.  Scratch rows and
+// tickets are static device arrays of the library (tickets reset themselves); launches that may overlap in time (the main
+// stream and the weight-gradient side stream) take different scratch slots, handed out round-robin by the launcher.
+#define RED_SLOTS 64
+#define RED_MAXSLICE 32
+#define RED_MAXW 2624                 // widest table: 27 x 96 pooling-conv weight gradients (2592), padded to 64
+__device__ float g_red_scratch[RED_SLOTS][RED_MAXSLICE][RED_MAXW];
+__device__ unsigned g_red_ticket[RED_SLOTS][RED_MAXW / 64];
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
                                                               float* __restrict__ out_a, float* __restrict__ out_b,
-                                                              int split, int accumulate) {
+                                                              int split, int accumulate, int slot) {
     __shared__ float red[4][64];
+    __shared__ unsigned last;
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + col;
-    const int per = (nparts + gridDim.y - 1) / gridDim.y;
+    const int nsl = gridDim.y;
+    const int per = (nparts + nsl - 1) / nsl;
     const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
     float s = 0.f;
     if (j < width)
         for (int b = b0 + sl; b < b1; b += 4) s += part[(int64_t)b * width + j];
     red[sl][col] = s;
     __syncthreads();
-    if (sl == 0 && j < width) {
+    if (sl != 0) {
+        if (nsl == 1) return;
+    } else {
         s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        float* o = (j < split) ? out_a + j : out_b + (j - split);
-        if (gridDim.y > 1) atomicAdd(o, s);
-        else *o = accumulate ? *o + s : s;
+        if (nsl == 1) {
+            if (j < width) {
+                float* o = (j < split) ? out_a + j : out_b + (j - split);
+                *o = accumulate ? *o + s : s;
+            }
+            return;
+        }
+        g_red_scratch[slot][blockIdx.y][j < RED_MAXW ? j : 0] = s;
     }
+    // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases and takes a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&g_red_ticket[slot][blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)nsl - 1u) ? 1u : 0u;
+        if (last) {
+            __hip_atomic_store(&g_red_ticket[slot][blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last || sl != 0 || j >= width) return;
+    float tot = 0.f;
+    for (int y = 0; y < nsl; ++y) tot += __builtin_nontemporal_load(&g_red_scratch[slot][y][j]);
+    float* o = (j < split) ? out_a + j : out_b + (j - split);
+    *o = accumulate ? *o + tot : tot;
 }
 
-static int launch_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
+// shared by every file of the library that reduces a partial table (declared in common.h)
+int mvit_internal_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
                                   hipStream_t st) {
+    static unsigned next_slot = 0;
+    if (width > RED_MAXW) return MVIT_EUNSUPPORTED;
     int slices = nparts / 64;
-    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-    if (slices > 1 && !accumulate) {
-        if (hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)(split < width ? split : width), st) != hipSuccess) return MVIT_ELAUNCH;
-        if (width > split && hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)(width - split), st) != hipSuccess) return MVIT_ELAUNCH;
-    }
+    slices = slices < 1 ? 1 : (slices > RED_MAXSLICE ? RED_MAXSLICE : slices);
+    const int slot = (int)(next_slot++ % RED_SLOTS);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
-                       accumulate);
+                       accumulate, slot);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+static int launch_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
+                                  hipStream_t st) {
+    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st);
 }
 
 #define LN_BWD_MAXBLK 1024     // 4 workgroups per CU: the kernel is HBM-bound

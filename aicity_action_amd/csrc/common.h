@@ -170,3 +170,7 @@ static inline bool side_join(SideStream* s, hipStream_t st) {
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// deterministic column sums of a [nparts][width] fp32 partial table (backward_rowops.hip)
+int mvit_internal_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
+                                  hipStream_t st);

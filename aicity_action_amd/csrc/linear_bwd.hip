@@ -41,7 +41,7 @@ template <typename TA, typename TD>
 __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ a, int64_t lda, const TD* __restrict__ dy,
                                                          int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
                                                          float* __restrict__ dW, float* __restrict__ db, int64_t M, int N, int K,
-                                                         int mchunk) {
+                                                         int mchunk, float* __restrict__ part) {
     // 3 waves; wave w owns the 32(n) x 96(k) strip n-block w of the 96x96 tile (48 accumulator registers -> 3-4
     // workgroups per CU) and walks all four 16-row k-steps of every 64-row slab; no cross-wave reduction.
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * WG_ROWB];
@@ -125,7 +125,24 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
             if (do_bias) bacc = mfma16(df, ones, bacc);   // dy^T . 1 = bias gradient
         }
     }
-    // acc[kb][i]: row n = 32*wave + (i&3) + 8(i>>2) + 4h, col k = 32kb + r  -> 128 contiguous bytes per half-wave atomic
+    // acc[kb][i]: row n = 32*wave + (i&3) + 8(i>>2) + 4h, col k = 32kb + r  -> 128 contiguous bytes per half-wave
+    // part != nullptr: this M chunk's tile goes to its own slab (plain stores; wgrad_reduce_kernel adds the slabs in chunk
+    // order: bit-reproducible).  part == nullptr: legacy float atomics straight into dW / db.
+    if (part) {
+        float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
+                oW[(int64_t)n * K + k0 + 32 * kb + r] = acc[kb][i];
+            }
+        if (do_bias && r == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oW[(int64_t)N * K + n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h] = bacc[i];
+        }
+        return;
+    }
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
@@ -183,7 +200,7 @@ __device__ __forceinline__ bf16x8 wb_join(const bf16x4 (&f)[2]) {
 __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restrict__ a, int64_t lda,
                                                            const bf16_t* __restrict__ dy, int64_t ldd,
                                                            float* __restrict__ dW, float* __restrict__ db, int64_t M, int N,
-                                                           int K, int mchunk) {
+                                                           int K, int mchunk, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntq = (K + WB_BQ - 1) / WB_BQ;      // ragged last tiles (N, K multiples of 32): sources clamped, results masked
     const int n0 = (blockIdx.x / ntq) * WB_BP, k0 = (blockIdx.x % ntq) * WB_BQ;
@@ -290,6 +307,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
 #undef MM
     }
     // acc[pb][qb][i]: row n = n0 + 64wp + 32pb + (i&3) + 8(i>>2) + 4h, col k = k0 + 96wq + 32qb + r -> 128 contiguous bytes
+    if (part) {      // this M chunk's tile to its own slab, plain stores (summed in chunk order by wgrad_reduce_kernel)
+        float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const int kk = k0 + 96 * wq + 32 * qb + r;
+                    if (n < N && kk < K) oW[(int64_t)n * K + kk] = acc[pb][qb][i];
+                }
+        if (do_bias && r == 0) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (n < N) oW[(int64_t)N * K + n] = bacc[pb][i];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
@@ -319,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ dy,
                                                         int64_t ldd, const float* __restrict__ row_scale, int64_t rps,
                                                         float* __restrict__ dW, float* __restrict__ db, int64_t M, int N, int K,
-                                                        int mchunk) {
+                                                        int mchunk, float* __restrict__ part) {
     __shared__ float Ds[16][68];
     __shared__ float As[16][68];
     const int ntk = (K + 63) / 64;
@@ -363,6 +403,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dr[i], ar[j], acc[i][j]);
         }
     }
+    if (part) {
+        float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + ty * 4 + i, k = k0 + tx * 4 + j;
+                if (n < N && k < K) oW[(int64_t)n * K + k] = acc[i][j];
+            }
+        if (do_bias && tid < 64 && n0 + tid < N) oW[(int64_t)N * K + n0 + tid] = bsum;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -373,35 +425,92 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
     if (do_bias && tid < 64 && n0 + tid < N) atomicAdd(db + n0 + tid, bsum);
 }
 
-// dW (and db when given: db[n] += sum_m scale*dy[m][n]) must be zeroed (or hold the value to accumulate onto) by the caller.
-extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                                 const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
-                                 int K, int act_dtype, void* stream) {
-    if (!a || !dy || !dW || M <= 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
-    if (row_scale && rows_per_scale <= 0) return MVIT_EINVAL;
-    hipStream_t st = as_stream(stream);
-    // M chunk per workgroup: enough workgroups to fill the chip (~2048), at least 1024 rows to amortise the atomics
+// dW[i] += sum_c part[c][i] (i < N*K), db[n] += sum_c part[c][N*K + n], chunks added in index order: the fixed-order second stage
+// of the slab form of the three kernels above
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nch, int64_t stride, float* __restrict__ dW,
+                                                           float* __restrict__ db, int64_t nk, int n) {
+    const int64_t tot4 = (nk + n) / 4;         // N, K multiples of 4 in every caller (checked by the launcher)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 256) {
+        float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int c = 1; c < nch; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(part + c * stride + 4 * i);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float* o = 4 * i < nk ? dW + 4 * i : (db ? db + (4 * i - nk) : nullptr);
+        if (o) {
+            float4 cur = *reinterpret_cast<const float4*>(o);
+            cur.x += s.x; cur.y += s.y; cur.z += s.z; cur.w += s.w;
+            *reinterpret_cast<float4*>(o) = cur;
+        }
+    }
+}
+
+// Launch plan shared by the entry point and the workspace query.
+struct WgradPlan { int path; int64_t nch; int mchunk; };     // path: 0 fp32 VALU, 1 big MFMA tile, 2 96x96 MFMA tile, < 0 error
+static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, bool scaled, int64_t M, int N, int K, int act_dtype) {
+    WgradPlan p = {MVIT_EUNSUPPORTED, 0, 0};
+    // M chunk per workgroup: enough workgroups to fill the chip (~2048), at least 1024 rows
     const int64_t tiles = act_dtype == MVIT_F32 ? (int64_t)((N + 63) / 64) * ((K + 63) / 64) : (int64_t)(N / 96) * (K / 96);
     int64_t mc = (M * (tiles > 0 ? tiles : 1) + 2047) / 2048;
     mc = mc < WG_MCHUNK ? WG_MCHUNK : mc;
     mc = (mc + 63) / 64 * 64;
-    const int mchunk = (int)mc;
-    const int64_t mchunks = (M + mchunk - 1) / mchunk;
-    if (mchunks > 65535) return MVIT_EINVAL;
+    const int64_t mchunks = (M + mc - 1) / mc;
+    if (mchunks > 65535) { p.path = MVIT_EINVAL; return p; }
     if (act_dtype == MVIT_F32) {
-        if (a_dtype != MVIT_F32 || dy_dtype != MVIT_F32) return MVIT_EDTYPE;
-        if ((lda & 3) || (ldd & 3)) return MVIT_EUNSUPPORTED;
-        dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)mchunks);
-        hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
-                           rows_per_scale, dW, db, M, N, K, mchunk);
-        MVIT_LAUNCH_CHECK();
-        return MVIT_OK;
+        if (a_dtype != MVIT_F32 || dy_dtype != MVIT_F32) { p.path = MVIT_EDTYPE; return p; }
+        if ((lda & 3) || (ldd & 3)) return p;
+        p.path = 0; p.nch = mchunks; p.mchunk = (int)mc;
+        return p;
     }
-    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
-    if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return MVIT_EUNSUPPORTED;
+    if (act_dtype != MVIT_BF16) { p.path = MVIT_EDTYPE; return p; }
+    if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return p;
     static const bool use_big = getenv("MVIT_WGRAD_NO_BIG") == nullptr;
-    if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !row_scale && N % 32 == 0 && K % 32 == 0 && N >= 32 && K >= 32 && M % 64 == 0 &&
+    if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !scaled && N % 32 == 0 && K % 32 == 0 && N >= 32 && K >= 32 && M % 64 == 0 &&
         64 * lda < (1ll << 31) && 64 * ldd < (1ll << 31)) {
+        const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
+        // M chunks: fewer, longer chunks (each ends with a 128x192 fp32 tile going to its slab / to atomics) as long as the grid
+        // stays inside ONE round of resident workgroups (512 slots): 384 measured best for the 12-24-tile layers, 256 for layers
+        // with few tiles (MVIT_WGRAD_WGS overrides)
+        static const int wg_env = getenv("MVIT_WGRAD_WGS") ? atoi(getenv("MVIT_WGRAD_WGS")) : 0;
+        const int wg_target = wg_env > 0 ? wg_env : (bt <= 8 ? 256 : 384);
+        int64_t nch = (wg_target + bt - 1) / bt;
+        int64_t bmc = ((M / 64 + nch - 1) / nch) * 64;          // rows per chunk, multiple of 64
+        if (bmc < 512) bmc = 512;
+        p.path = 1; p.nch = (M + bmc - 1) / bmc; p.mchunk = (int)bmc;
+        return p;
+    }
+    p.path = 2; p.nch = mchunks; p.mchunk = (int)mc;
+    return p;
+}
+
+// fp32 workspace bytes of the deterministic (slab) form of mvit_linear_wgrad2 for this problem; 0 if it has no such form
+extern "C" int64_t mvit_linear_wgrad_workspace_bytes(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, int has_row_scale, int64_t M,
+                                                     int N, int K, int act_dtype) {
+    const WgradPlan p = wgrad_plan(a_dtype, lda, dy_dtype, ldd, has_row_scale != 0, M, N, K, act_dtype);
+    if (p.path < 0 || (N & 3) || (K & 3)) return 0;
+    return p.nch * ((int64_t)N * K + N) * (int64_t)sizeof(float);
+}
+
+// dW (and db when given: db[n] += sum_m scale*dy[m][n]) must be zeroed (or hold the value to accumulate onto) by the caller.
+// workspace (>= mvit_linear_wgrad_workspace_bytes): every M chunk writes its partial dW / db to its own slab and a second kernel
+// adds the slabs in chunk order -- bit-reproducible.  workspace == NULL: the chunks meet in fp32 atomics (order-dependent sums).
+extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                                  const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                                  int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream) {
+    if (!a || !dy || !dW || M <= 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
+    if (row_scale && rows_per_scale <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const WgradPlan p = wgrad_plan(a_dtype, lda, dy_dtype, ldd, row_scale != nullptr, M, N, K, act_dtype);
+    if (p.path < 0) return p.path;
+    const int64_t stride = (int64_t)N * K + N;
+    float* part = nullptr;
+    if (workspace && !(N & 3) && !(K & 3) && workspace_bytes >= p.nch * stride * (int64_t)sizeof(float)) part = workspace;
+    const int mchunk = p.mchunk;
+    if (p.path == 0) {
+        dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)p.nch);
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
+                           rows_per_scale, dW, db, M, N, K, mchunk, part);
+    } else if (p.path == 1) {
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess)
@@ -409,29 +518,32 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
             attr_done = true;
         }
         const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
-        // M chunks: every workgroup ends with a 128x192 fp32 tile of atomics (96 KiB; ~1.3 TB/s chip-wide, 25-45 % of the kernel at
-        // 512 workgroups), so fewer, longer chunks win as long as the grid stays inside ONE round of resident workgroups (512
-        // slots): 384 measured best for the 12-24-tile layers, 256 for layers with few tiles (MVIT_WGRAD_WGS overrides)
-        static const int wg_env = getenv("MVIT_WGRAD_WGS") ? atoi(getenv("MVIT_WGRAD_WGS")) : 0;
-        const int wg_target = wg_env > 0 ? wg_env : (bt <= 8 ? 256 : 384);
-        int64_t nch = (wg_target + bt - 1) / bt;
-        int64_t bmc = ((M / 64 + nch - 1) / nch) * 64;          // rows per chunk, multiple of 64
-        if (bmc < 512) bmc = 512;
-        nch = (M + bmc - 1) / bmc;
-        dim3 bgrid((unsigned)bt, (unsigned)nch);
-        hipLaunchKernelGGL(wgrad_big_kernel, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K, (int)bmc);
-        MVIT_LAUNCH_CHECK();
-        return MVIT_OK;
-    }
-    dim3 grid((N / 96) * (K / 96), (unsigned)mchunks);
+        dim3 bgrid((unsigned)bt, (unsigned)p.nch);
+        hipLaunchKernelGGL(wgrad_big_kernel, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K,
+                           mchunk, part);
+    } else {
+        dim3 grid((N / 96) * (K / 96), (unsigned)p.nch);
 #define WG(TA, TD) \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(192), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, db, M, N, K, mchunk)
-    if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16) WG(bf16_t, bf16_t);
-    else if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_F32) WG(bf16_t, float);
-    else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_F32) WG(float, float);
-    else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_BF16) WG(float, bf16_t);
-    else return MVIT_EDTYPE;
+        hipLaunchKernelGGL((wgrad_mfma_kernel<TA, TD>), grid, dim3(192), 0, st, (const TA*)a, lda, (const TD*)dy, ldd, row_scale, rows_per_scale, dW, db, M, N, K, mchunk, part)
+        if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16) WG(bf16_t, bf16_t);
+        else if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_F32) WG(bf16_t, float);
+        else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_F32) WG(float, float);
+        else if (a_dtype == MVIT_F32 && dy_dtype == MVIT_BF16) WG(float, bf16_t);
+        else return MVIT_EDTYPE;
 #undef WG
+    }
     MVIT_LAUNCH_CHECK();
+    if (part) {
+        int64_t blocks = ((stride / 4) + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, (int)p.nch, stride, dW, db, (int64_t)N * K, N);
+        MVIT_LAUNCH_CHECK();
+    }
     return MVIT_OK;
+}
+
+extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                                 const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                                 int K, int act_dtype, void* stream) {
+    return mvit_linear_wgrad2(a, a_dtype, lda, dy, dy_dtype, ldd, row_scale, rows_per_scale, dW, db, M, N, K, act_dtype, nullptr, 0, stream);
 }

@@ -645,16 +645,22 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
         }
         __syncthreads();
     }
-    // combine the ROWS threads that share a channel pair, then one partial row per workgroup
+    // combine the ROWS threads that share a channel pair in ROW ORDER (a fixed summation order: LDS float atomics would add in
+    // arrival order and make the weight gradient differ in its last bits from run to run), then one partial row per workgroup
     float* red = reinterpret_cast<float*>(smem);   // [2592]
-    for (int i = tid; i < 2592; i += P::NT) red[i] = 0.f;
-    __syncthreads();
+    __syncthreads();                               // everyone is done with the tiles this aliases
+    for (int rr = 0; rr < P::ROWS; ++rr) {
+        if (row == rr) {
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        atomicAdd(&red[(2 * cp) * 27 + t], acc[t][0]);
-        atomicAdd(&red[(2 * cp + 1) * 27 + t], acc[t][1]);
+            for (int t = 0; t < 27; ++t) {
+                float* r0 = &red[(2 * cp) * 27 + t];
+                float* r1 = &red[(2 * cp + 1) * 27 + t];
+                *r0 = rr == 0 ? acc[t][0] : *r0 + acc[t][0];
+                *r1 = rr == 0 ? acc[t][1] : *r1 + acc[t][1];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* prow = part + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2592;
     for (int i = tid; i < 2592; i += P::NT) prow[i] = red[i];
 }

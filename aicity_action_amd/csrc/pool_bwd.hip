@@ -182,41 +182,11 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__
     block_reduce(ab, 1);
 }
 
-// out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b.  blockIdx.y slices the partial
-// rows (a few thousand rows of 96..2592 floats: one column block per workgroup cannot pull the bandwidth); with more than one
-// slice the slices meet in fp32 atomics on the (pre-zeroed or accumulated-into) output.
-__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ part, int nparts, int width, float* __restrict__ out_a,
-                                                          float* __restrict__ out_b, int split, int accumulate) {
-    __shared__ float red[4][64];
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + col;
-    const int per = (nparts + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
-    float s = 0.f;
-    if (j < width)
-        for (int b = b0 + sl; b < b1; b += 4) s += part[(int64_t)b * width + j];
-    red[sl][col] = s;
-    __syncthreads();
-    if (sl == 0 && j < width) {
-        s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-        float* o = (j < split) ? out_a + j : out_b + (j - split);
-        if (gridDim.y > 1) atomicAdd(o, s);
-        else *o = accumulate ? *o + s : s;
-    }
-}
-
+// out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b: the library's deterministic
+// single-launch column reduce (backward_rowops.hip: row slices parked in scratch, the last-arriving slice adds them in order)
 static int launch_pool_reduce(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
                               hipStream_t st) {
-    int slices = nparts / 64;
-    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
-    if (slices > 1 && !accumulate) {
-        if (hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)(split < width ? split : width), st) != hipSuccess) return MVIT_ELAUNCH;
-        if (width > split && hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)(width - split), st) != hipSuccess) return MVIT_ELAUNCH;
-    }
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
-                       accumulate);
-    MVIT_LAUNCH_CHECK();
-    return MVIT_OK;
+    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st);
 }
 
 template <typename TA>
@@ -454,9 +424,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_saved_kernel(const TA* __rest
                                                                 TA* __restrict__ dconv, float* __restrict__ part, int64_t total) {
     constexpr int CW = 16 / sizeof(TA);
     constexpr int NCH = 24 / CW;
-    __shared__ float red[192];
-    if (threadIdx.x < 192) red[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float red[4][192];        // one row per wave, added in wave order below (LDS float atomics would sum in arrival order)
     const int j = threadIdx.x & 3;
     float g[24], dg[24], db[24];
 #pragma unroll
@@ -522,12 +490,13 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_saved_kernel(const TA* __rest
                 bsum += __shfl_xor(bsum, off, 64);
             }
             if ((threadIdx.x & 63) < 4) {
-                atomicAdd(&red[c], a);
-                atomicAdd(&red[96 + c], bsum);
+                red[threadIdx.x >> 6][c] = a;
+                red[threadIdx.x >> 6][96 + c] = bsum;
             }
         }
     __syncthreads();
-    if (threadIdx.x < 192) part[(int64_t)blockIdx.x * 192 + threadIdx.x] = red[threadIdx.x];
+    if (threadIdx.x < 192)
+        part[(int64_t)blockIdx.x * 192 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // dconv: caller-provided scratch, same shape/type as dout.  dqkv slice is fully overwritten.

@@ -12,7 +12,7 @@
 #define SB_PW 35
 __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict__ clip, const float* __restrict__ dx,
                                                          float* __restrict__ dW, int B, int T, int S, int To, int So,
-                                                         int tiles_x, int tiles_y) {
+                                                         int tiles_x, int tiles_y, float* __restrict__ part) {
     __shared__ float patch[SB_PW * SB_PW];
     __shared__ __attribute__((aligned(16))) float dt_tile[64 * 96];
     const int tid = threadIdx.x;
@@ -71,12 +71,31 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict
             }
         }
     }
-    if (on) {
+    if (on) {      // part: this workgroup's own [96][441] slab (plain stores; slab_sum_kernel adds them in workgroup order)
+        float* o = part ? part + (int64_t)blockIdx.x * (96 * 441) : dW;
 #pragma unroll
         for (int p = 0; p < 9; ++p)
 #pragma unroll
             for (int k = 0; k < 10; ++k)
-                if (k < ntap) atomicAdd(dW + (int64_t)c * 441 + p * 49 + tap0 + k, acc[p][k]);
+                if (k < ntap) {
+                    if (part) o[(int64_t)c * 441 + p * 49 + tap0 + k] = acc[p][k];
+                    else atomicAdd(o + (int64_t)c * 441 + p * 49 + tap0 + k, acc[p][k]);
+                }
+    }
+}
+
+// out[i] += sum_p part[p][i], p in index order (float4 per thread): second stage of the slab form of the stem weight gradient
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ part, int nparts, int64_t stride, float* __restrict__ out,
+                                                       int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int p = 1; p < nparts; ++p) {
+            const float4 t = *reinterpret_cast<const float4*>(part + p * stride + 4 * i);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float4 cur = *reinterpret_cast<const float4*>(out + 4 * i);
+        cur.x += s.x; cur.y += s.y; cur.z += s.z; cur.w += s.w;
+        *reinterpret_cast<float4*>(out + 4 * i) = cur;
     }
 }
 
@@ -100,7 +119,8 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict
 typedef __attribute__((address_space(3))) bf16x4 sw_lds_b4;
 
 __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __restrict__ clip, const float* __restrict__ dxg,
-                                                              float* __restrict__ dW, int B, int T, int S, int To, int So) {
+                                                              float* __restrict__ dW, int B, int T, int S, int To, int So,
+                                                              float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) char smem[SW_PBYTES + SW_DBYTES];
     bf16_t* sP = reinterpret_cast<bf16_t*>(smem);
     char* sD = smem + SW_PBYTES;
@@ -205,79 +225,114 @@ __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __res
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int c = 32 * cb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    atomicAdd(dW + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx, acc[cb][kb][i]);
+                    // part: slab of this row group (the three input-channel workgroups of a group write disjoint columns)
+                    if (part) part[(int64_t)(blockIdx.x / 3) * (96 * 441) + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx] = acc[cb][kb][i];
+                    else atomicAdd(dW + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx, acc[cb][kb][i]);
                 }
         }
     }
 }
 
-// dpos_s[hw][c] = sum_{b,t} dx[b][t][hw][c] ;  dpos_t[t][c] = sum_{b,hw} dx[b][t][hw][c]  (the latter via fp32 atomics
-// on T*96 outputs after a block-level partial sum)
+// dpos_s[hw][c] += sum_{t,b} dx[b][t][hw][c] ;  dpos_t[t][c] += sum_{b,hw} dx[b][t][hw][c].
+// One workgroup per 8 spatial positions walks all (t, b) in a fixed order: dpos_s is complete in registers (no atomics);
+// the workgroup's partial of dpos_t goes to part[block][To*96] (part != NULL: summed over blocks by the library's ordered
+// column reduce) or, legacy, to fp32 atomics.
 __global__ __launch_bounds__(256) void stem_pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dps,
-                                                           float* __restrict__ dpt, int B, int To, int HW) {
+                                                           float* __restrict__ dpt, int B, int To, int HW, float* __restrict__ part) {
     __shared__ float red[8][96];
     const int hw0 = blockIdx.x * 8;
     const int c4 = threadIdx.x % 24, r = threadIdx.x / 24;   // 10 row slots, 8 used
-    const int t = blockIdx.y;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int hw = hw0 + r;
     const bool ok = r < 8 && hw < HW;
-    if (ok)
-        for (int b = 0; b < B; ++b) {
-            const float4 v = load4(dx + (((int64_t)b * To + t) * HW + hw) * 96 + 4 * c4);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-    if (ok) {   // spatial: one atomic per (hw,c) per t  (To atomics per output element)
-        atomicAdd(dps + (int64_t)hw * 96 + 4 * c4, acc.x); atomicAdd(dps + (int64_t)hw * 96 + 4 * c4 + 1, acc.y);
-        atomicAdd(dps + (int64_t)hw * 96 + 4 * c4 + 2, acc.z); atomicAdd(dps + (int64_t)hw * 96 + 4 * c4 + 3, acc.w);
-    }
-    if (r < 8) *reinterpret_cast<float4*>(&red[r][4 * c4]) = ok ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    if (threadIdx.x < 96) {
-        float s = 0.f;
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < To; ++t) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok)
+            for (int b = 0; b < B; ++b) {
+                const float4 v = load4(dx + (((int64_t)b * To + t) * HW + hw) * 96 + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+        __syncthreads();
+        if (r < 8) *reinterpret_cast<float4*>(&red[r][4 * c4]) = acc;
+        __syncthreads();
+        if (threadIdx.x < 96) {
+            float s = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) s += red[rr][threadIdx.x];
-        atomicAdd(dpt + t * 96 + threadIdx.x, s);
+            for (int rr = 0; rr < 8; ++rr) s += red[rr][threadIdx.x];
+            if (part) part[((int64_t)blockIdx.x * To + t) * 96 + threadIdx.x] = s;
+            else atomicAdd(dpt + t * 96 + threadIdx.x, s);
+        }
+    }
+    if (ok) {
+        float4 cur = load4(dps + (int64_t)hw * 96 + 4 * c4);
+        cur.x += tot.x; cur.y += tot.y; cur.z += tot.z; cur.w += tot.w;
+        *reinterpret_cast<float4*>(dps + (int64_t)hw * 96 + 4 * c4) = cur;
     }
 }
 
 // dW, dpos_s, dpos_t are ACCUMULATED into (caller zeroes them once per step).
-extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
-                             int B, int T, int S, void* stream) {
-    if (!clip || !dx || !dW || !dpos_spatial || !dpos_temporal || B <= 0 || T <= 0 || S <= 0) return MVIT_EINVAL;
-    if ((T & 1) || (S & 3)) return MVIT_EUNSUPPORTED;
-    hipStream_t st = as_stream(stream);
-    const int To = T / 2, So = S / 4;
-    const int tiles_x = (So + 7) / 8, tiles_y = (So + 7) / 8;
-    const int ntiles = B * To * tiles_x * tiles_y;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, st, clip, dx, dW, B, T, S, To, So,
-                       tiles_x, tiles_y);
-    MVIT_LAUNCH_CHECK();
-    dim3 grid((So * So + 7) / 8, To);
-    hipLaunchKernelGGL(stem_pos_bwd_kernel, grid, dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So);
-    MVIT_LAUNCH_CHECK();
-    return MVIT_OK;
-}
-
 // act_dtype selects the weight-gradient kernel: MVIT_F32 -> exact fp32 VALU kernel, MVIT_BF16 -> matrix-core kernel on
 // 16-bit copies of the clip rows and token gradients (fp32 accumulation).  Positional-embedding gradients are fp32 sums.
-extern "C" int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
-                              int B, int T, int S, int act_dtype, void* stream) {
-    if (act_dtype == MVIT_F32) return mvit_stem_bwd(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, stream);
-    if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+// workspace (mvit_stem_bwd_workspace_bytes): per-workgroup partial slabs added in a fixed order -> bit-reproducible gradients;
+// NULL: the workgroups meet in fp32 atomics.
+static int stem_wgrad_groups(int B, int T, int S, int act_dtype, bool* mfma) {
+    const int To = T / 2, So = S / 4;
+    *mfma = act_dtype == MVIT_BF16 && So <= 112;
+    if (*mfma) {
+        const int64_t nrows = (int64_t)B * To * So;
+        return (int)(nrows < 170 ? nrows : 170);          // x3 input channels = 510 workgroups (2 per CU by LDS)
+    }
+    const int ntiles = B * To * ((So + 7) / 8) * ((So + 7) / 8);
+    return ntiles < 512 ? ntiles : 512;
+}
+extern "C" int64_t mvit_stem_bwd_workspace_bytes(int B, int T, int S, int act_dtype) {
+    if (B <= 0 || T <= 0 || S <= 0 || (T & 1) || (S & 3)) return 0;
+    bool mfma;
+    const int groups = stem_wgrad_groups(B, T, S, act_dtype, &mfma);
+    const int To = T / 2, So = S / 4;
+    const int64_t pos_blocks = (So * So + 7) / 8;
+    return ((int64_t)groups * 96 * 441 + pos_blocks * To * 96) * (int64_t)sizeof(float);
+}
+extern "C" int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
+                              int B, int T, int S, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream) {
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (!clip || !dx || !dW || !dpos_spatial || !dpos_temporal || B <= 0 || T <= 0 || S <= 0) return MVIT_EINVAL;
     if ((T & 1) || (S & 3)) return MVIT_EUNSUPPORTED;
-    const int To = T / 2, So = S / 4;
-    if (So > 112) return mvit_stem_bwd(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, stream);
     hipStream_t st = as_stream(stream);
-    const int64_t nrows = (int64_t)B * To * So;
-    int nwg = (int)(nrows < 170 ? nrows : 170);          // x3 input channels = 510 workgroups (2 per CU by LDS)
-    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(3 * nwg), dim3(192), 0, st, clip, dx, dW, B, T, S, To, So);
+    const int To = T / 2, So = S / 4;
+    bool mfma;
+    const int groups = stem_wgrad_groups(B, T, S, act_dtype, &mfma);
+    const int pos_blocks = (So * So + 7) / 8;
+    float* wpart = nullptr;
+    float* ppart = nullptr;
+    if (workspace && workspace_bytes >= mvit_stem_bwd_workspace_bytes(B, T, S, act_dtype)) {
+        wpart = workspace;
+        ppart = workspace + (int64_t)groups * 96 * 441;
+    }
+    if (mfma) {
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(3 * groups), dim3(192), 0, st, clip, dx, dW, B, T, S, To, So, wpart);
+    } else {
+        const int tiles_x = (So + 7) / 8, tiles_y = (So + 7) / 8;
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(groups), dim3(512), 0, st, clip, dx, dW, B, T, S, To, So, tiles_x, tiles_y, wpart);
+    }
     MVIT_LAUNCH_CHECK();
-    dim3 grid((So * So + 7) / 8, To);
-    hipLaunchKernelGGL(stem_pos_bwd_kernel, grid, dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So);
+    if (wpart) {
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(42), dim3(256), 0, st, wpart, groups, (int64_t)96 * 441, dW, (int64_t)96 * 441 / 4);
+        MVIT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(stem_pos_bwd_kernel, dim3(pos_blocks), dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So, ppart);
     MVIT_LAUNCH_CHECK();
+    if (ppart) return mvit_internal_reduce_partials(ppart, pos_blocks, To * 96, dpos_temporal, dpos_temporal, To * 96, 1, st);
     return MVIT_OK;
+}
+extern "C" int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
+                              int B, int T, int S, int act_dtype, void* stream) {
+    return mvit_stem_bwd3(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, act_dtype, nullptr, 0, stream);
+}
+extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
+                             int B, int T, int S, void* stream) {
+    return mvit_stem_bwd3(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, MVIT_F32, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

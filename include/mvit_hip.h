@@ -156,6 +156,15 @@ int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dt
 int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
                       const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
                       int K, int act_dtype, void* stream);
+/* The same with a caller-provided fp32 workspace of mvit_linear_wgrad_workspace_bytes(...) bytes: every M chunk writes its partial
+ * dW / db into its own slab and a second kernel adds the slabs in chunk order, so the result is bit-reproducible (the reference's
+ * fp32 step is).  Without a workspace (NULL, or mvit_linear_wgrad) the chunks meet in float atomics and the last
+ * bits depend on arrival order. */
+int64_t mvit_linear_wgrad_workspace_bytes(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, int has_row_scale, int64_t M, int N,
+                                          int K, int act_dtype);
+int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                       const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                       int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[n] (+)= sum_m row_scale[m/rps] * a[m][n]  (bias gradients).  workspace >= mvit_colsum_workspace_bytes(N). */
 int64_t mvit_colsum_workspace_bytes(int N);
@@ -209,6 +218,11 @@ int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spa
  * 16-bit operands, fp32 accumulate). */
 int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
                    int T, int S, int act_dtype, void* stream);
+/* The same with a caller-provided fp32 workspace (mvit_stem_bwd_workspace_bytes): per-workgroup partial slabs of dW and of
+ * dpos_temporal are added in a fixed order, so the three gradients are bit-reproducible; NULL: float atomics. */
+int64_t mvit_stem_bwd_workspace_bytes(int B, int T, int S, int act_dtype);
+int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B, int T, int S,
+                   int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* Head, training variant.  mvit_head_ln_partial = stage 1 of mvit_head_fwd (workspace [B][ceil(N/32)][C]);
  * mvit_head_project_train: z = mean * mask (dropout mask holding 0 or 1/(1-p), or NULL), logits = z W^T + b;
