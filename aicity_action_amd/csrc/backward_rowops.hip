@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 // out[j] (+)= sum_b part[b][j]: deterministic column sums of a [nparts][width] partial table in ONE launch, no float atomics.
 // grid = (64-column blocks, row slices).  Every workgroup sums its slice of the rows (4 interleaved row groups, fixed order)
 // and, when there is more than one slice, parks the result in a per-launch scratch row; the slice that ARRIVES LAST for a
-// column block (agent-scope release + ticket, acquire on the last arriver: cdna guide G16 counter form) adds the parked rows
+// column block (write-through stores + ticket, L1-bypassing loads on the last arriver: cdna guide G16, sc1 form) adds the parked rows
 // in slice order -- so the summation order is a function of the launch geometry only, never of timing.  Scratch rows and
 // tickets are static device arrays of the library (tickets reset themselves); launches that may overlap in time (the main
 // stream and the weight-gradient side stream) take different scratch slots, handed out round-robin by the launcher.
@@ -138,26 +138,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
             }
             return;
         }
-        g_red_scratch[slot][blockIdx.y][j < RED_MAXW ? j : 0] = s;
+        // write-through (sc1) store: visible to every CU without a release fence once this wave's vmcnt has drained
+        __hip_atomic_store(&g_red_scratch[slot][blockIdx.y][j < RED_MAXW ? j : 0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases and takes a ticket
+    // publish (cdna guide G16, sc1 form): the storing wave drains its stores, the workgroup meets, ONE lane takes a ticket; the
+    // last arriver reads the parked rows with sc1 loads (L1 bypassed: no acquire fence needed)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(&g_red_ticket[slot][blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (t == (unsigned)nsl - 1u) ? 1u : 0u;
-        if (last) {
-            __hip_atomic_store(&g_red_ticket[slot][blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (last) __hip_atomic_store(&g_red_ticket[slot][blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     __syncthreads();
     if (!last || sl != 0 || j >= width) return;
     float tot = 0.f;
-    for (int y = 0; y < nsl; ++y) tot += __builtin_nontemporal_load(&g_red_scratch[slot][y][j]);
+    for (int y = 0; y < nsl; ++y) tot += __hip_atomic_load(&g_red_scratch[slot][y][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* o = (j < split) ? out_a + j : out_b + (j - split);
     *o = accumulate ? *o + tot : tot;
 }

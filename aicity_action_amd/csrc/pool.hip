@@ -646,23 +646,42 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
         __syncthreads();
     }
     // combine the ROWS threads that share a channel pair in ROW ORDER (a fixed summation order: LDS float atomics would add in
-    // arrival order and make the weight gradient differ in its last bits from run to run), then one partial row per workgroup
-    float* red = reinterpret_cast<float*>(smem);   // [2592]
-    __syncthreads();                               // everyone is done with the tiles this aliases
-    for (int rr = 0; rr < P::ROWS; ++rr) {
-        if (row == rr) {
+    // arrival order and make the weight gradient differ in its last bits from run to run): the rows park their 54 sums side by
+    // side, four rows per pass (4 x 2592 floats fit the tile storage this aliases), and every output is added up in row order
+    float* red = reinterpret_cast<float*>(smem);   // [4][2592]
+    static_assert(4 * 2592 * 4 <= P::IN_BYTES + 3 * P::NTOK * 96 * (int)sizeof(TA), "row slabs must fit");
+    constexpr int NOUT = (2592 + P::NT - 1) / P::NT;
+    float tot[NOUT];
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
-                float* r0 = &red[(2 * cp) * 27 + t];
-                float* r1 = &red[(2 * cp + 1) * 27 + t];
-                *r0 = rr == 0 ? acc[t][0] : *r0 + acc[t][0];
-                *r1 = rr == 0 ? acc[t][1] : *r1 + acc[t][1];
-            }
+    for (int o = 0; o < NOUT; ++o) tot[o] = 0.f;
+    for (int r0 = 0; r0 < P::ROWS; r0 += 4) {
+        __syncthreads();                           // everyone is done with what this aliases (tiles / the previous pass)
+        if (row >= r0 && row < r0 + 4) {
+            // parked as [tap][channel] with the channel PAIR of a thread adjacent: one 8-byte store per tap from the register pair
+            // the arithmetic keeps together (a [channel][tap] image lets the compiler merge stores across taps, which forces the
+            // 54 sums into consecutive registers for the whole kernel: 150 spilled registers in the main loop)
+#pragma unroll
+            for (int t = 0; t < 27; ++t)
+                *reinterpret_cast<float2*>(&red[(row - r0) * 2592 + t * 96 + 2 * cp]) = make_float2(acc[t][0], acc[t][1]);
         }
         __syncthreads();
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const int i = tid + P::NT * o;          // output index c * 27 + tap
+            if (i < 2592) {
+                const int c = i / 27, t = i - c * 27;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    if (r0 + rr < P::ROWS) tot[o] += red[rr * 2592 + t * 96 + c];
+            }
+        }
     }
     float* prow = part + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2592;
-    for (int i = tid; i < 2592; i += P::NT) prow[i] = red[i];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const int i = tid + P::NT * o;
+        if (i < 2592) prow[i] = tot[o];
+    }
 }
 
 template <typename TA, int S>

@@ -6,8 +6,8 @@
 kern=$1; out=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/traffic/f -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/traffic/w -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/traffic/f -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-forward-record "$@" > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/traffic/w -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-forward-record "$@" > /dev/null 2>&1
 python3 - <<PY
 import csv, glob, json, collections
 acc = collections.defaultdict(list)
