@@ -82,6 +82,7 @@ _SIGS = {
     "mvit_mt_chunk_bytes": (c_i, []),
     "mvit_grad_norm": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p]),
     "mvit_adamw_step": (c_i, [c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "mvit_adamw_step_dev": (c_i, [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_p]),
 }
 EXPORTS = tuple(_SIGS)
 

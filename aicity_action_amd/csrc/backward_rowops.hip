@@ -593,8 +593,13 @@ __global__ void gradnorm_finish_kernel(const float* __restrict__ part, int n, fl
 // AdamW, decoupled weight decay, bias correction (torch.optim.AdamW, amsgrad False); grads scaled by *coef (clip).
 __global__ __launch_bounds__(256) void adamw_chunks_kernel(const MtChunk* __restrict__ ch, const float* __restrict__ coef_ptr,
                                                            float lr, float beta1, float beta2, float eps, float bc1,
-                                                           float bc2_sqrt) {
+                                                           float bc2_sqrt, const float* __restrict__ hyper) {
     const MtChunk c = ch[blockIdx.x];
+    if (hyper) {        // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} from device memory: a captured (hipGraph) step replays with new values
+        lr = hyper[0];
+        bc1 = hyper[1];
+        bc2_sqrt = hyper[2];
+    }
     const float coef = coef_ptr ? coef_ptr[1] : 1.0f;
     // a non-finite global norm (NaN / inf loss or gradient) must not reach the parameters or the moments: skip the whole step
     // (bit test: the build uses -fno-honor-nans)
@@ -630,7 +635,18 @@ extern "C" int mvit_adamw_step(const void* chunk_table, int nchunks, const float
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_chunks_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream), (const MtChunk*)chunk_table, norm_coef,
-                       lr, beta1, beta2, eps, bc1, bc2s);
+                       lr, beta1, beta2, eps, bc1, bc2s, (const float*)nullptr);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
+// The same step with its per-iteration scalars {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read from device memory (3 floats): the
+// launch carries no value that changes from step to step, so it can sit in a captured hipGraph that is replayed every iteration.
+extern "C" int mvit_adamw_step_dev(const void* chunk_table, int nchunks, const float* norm_coef, const float* hyper, float beta1,
+                                   float beta2, float eps, void* stream) {
+    if (!chunk_table || nchunks <= 0 || !hyper) return MVIT_EINVAL;
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3(nchunks), dim3(256), 0, as_stream(stream), (const MtChunk*)chunk_table, norm_coef,
+                       0.f, beta1, beta2, eps, 1.f, 1.f, hyper);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }

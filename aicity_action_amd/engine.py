@@ -218,6 +218,24 @@ def check_nan_losses(loss):
         raise RuntimeError("ERROR: Got NaN losses {}".format(datetime.datetime.now()))
 
 
+_GRAPHED = {}
+
+
+def _graphed_step(model, optimizer, cfg, scaler):
+    """The GraphedTrainStep of (model, optimizer) when cfg.HIP.GRAPH_STEP asks for it (single rank, no loss scaler), else None."""
+    hip = getattr(cfg, "HIP", None)
+    if hip is None or not bool(getattr(hip, "GRAPH_STEP", False)):
+        return None
+    if (scaler is not None and scaler.is_enabled()) or du.get_world_size() > 1:
+        return None
+    key = (id(model), id(optimizer))
+    if key not in _GRAPHED:
+        from .graph_step import GraphedTrainStep
+        _GRAPHED.clear()                     # one live graph per process (its memory pool is private)
+        _GRAPHED[key] = GraphedTrainStep(model, optimizer, cfg, _loss, topks_correct)
+    return _GRAPHED[key]
+
+
 def train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, cfg):
     """One training epoch in the reference's step order (train_net.py:35-324, single-label branch).
 
@@ -230,11 +248,19 @@ def train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, 
     data_size = len(train_loader)
     dev = _device_of(model)
     world = du.get_world_size()
+    graphed = _graphed_step(model, optimizer, cfg, scaler)
     for cur_iter, (inputs, labels, _, meta) in enumerate(train_loader):
         inputs, labels = _to_device(inputs, dev), _to_device(labels, dev)
         lr = solver.get_lr_at_epoch(cfg, cur_epoch + float(cur_iter) / data_size)
         optimizer.set_lr(lr)
         train_meter.data_toc()
+        if graphed is not None:             # HIP.GRAPH_STEP: the whole step is one replayed hipGraph (graph_step.py)
+            stats = graphed.run(inputs[0], labels, lr)
+            train_meter.update_stats_async(stats, lr, inputs[0].size(0) * max(world, 1))
+            train_meter.iter_toc()
+            train_meter.log_iter_stats(cur_epoch, cur_iter)
+            train_meter.iter_tic()
+            continue
         preds = model(inputs)
         loss = _loss(cfg, preds, labels)
         optimizer.zero_grad()

@@ -117,6 +117,22 @@ class HipAdamW(object):
             self._n = 0
             self._grad_ptrs = ptrs
             return
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture (graph_step.GraphedTrainStep): no event waits allowed, and the copy node re-reads its host
+            # source at every replay -- so the table goes up from a pinned buffer of its own that is never written again (the
+            # gradients of a captured step live at fixed addresses in the graph's memory pool)
+            if getattr(self, "_cap_pinned", None) is None or self._cap_pinned.numel() != host.size:
+                raise RuntimeError("HipAdamW: call prepare_capture() before capturing a step (pinned memory cannot be allocated "
+                                   "while a stream is capturing)")
+            self._cap_pinned.numpy()[:] = host
+            self._table = torch.empty(host.size, dtype=torch.uint8, device=dev)
+            self._partials = torch.empty(len(rec), dtype=torch.float32, device=dev)
+            self._out2 = torch.empty(2, dtype=torch.float32, device=dev)
+            self._table.copy_(self._cap_pinned, non_blocking=True)
+            self._pin_ring = None
+            self._n = len(rec)
+            self._grad_ptrs = ptrs
+            return
         ring = self.__dict__.get("_pin_ring")
         if ring is None or ring[0][0].numel() != host.size or self._table is None or self._table.device != dev:
             ring = [[torch.empty(host.size, dtype=torch.uint8).pin_memory(), None] for _ in range(3)]
@@ -136,7 +152,32 @@ class HipAdamW(object):
         self._n = len(rec)
         self._grad_ptrs = ptrs
 
-    def step(self, max_norm=None, grad_scale=None):
+    def prepare_capture(self):
+        """Allocate, OUTSIDE the capture, the pinned buffer the captured step's chunk table is uploaded from (needs one eager
+        step before: the table size is the chunk count)."""
+        assert self._table is not None, "run one eager step first"
+        self._cap_pinned = torch.empty(self._table.numel(), dtype=torch.uint8).pin_memory()
+
+    def hyper_values(self, step=None):
+        """[lr, 1 - beta1^t, sqrt(1 - beta2^t)] of step t (default: the next one): what mvit_adamw_step_dev reads from device memory."""
+        t = self.step_count + 1 if step is None else step
+        # single-precision libm, exactly as mvit_adamw_step computes them on the host (so a captured step and an eager step agree
+        # to the last bit)
+        import ctypes
+        libm = getattr(HipAdamW, "_libm", None)
+        if libm is None:
+            libm = ctypes.CDLL("libm.so.6")
+            libm.powf.restype = ctypes.c_float
+            libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+            libm.sqrtf.restype = ctypes.c_float
+            libm.sqrtf.argtypes = [ctypes.c_float]
+            HipAdamW._libm = libm
+        f32 = lambda v: ctypes.c_float(v).value
+        bc1 = f32(1.0 - libm.powf(self.betas[0], float(t)))
+        bc2s = libm.sqrtf(f32(1.0 - libm.powf(self.betas[1], float(t))))
+        return [self.lr, bc1, bc2s]
+
+    def step(self, max_norm=None, grad_scale=None, hyper=None):
         """One clipped AdamW step.  max_norm None -> cfg.SOLVER.CLIP_GRAD_L2NORM (None/0 disables clipping).
         grad_scale (float): the gradients carry this loss-scale factor (HipGradScaler): they are unscaled inside the fused
         update, the clip acts on the unscaled norm, and the step is SKIPPED (returns None) when the norm is inf / nan.
@@ -166,8 +207,12 @@ class HipAdamW(object):
         else:
             _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, float(max_norm), _hip.ptr(self._partials),
                                         _hip.ptr(self._out2), st), "grad_norm")
-        _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
-                                     self.eps, self.step_count, st), "adamw")
+        if hyper is not None:       # per-iteration scalars from device memory (captured step)
+            _hip.check(L.mvit_adamw_step_dev(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), _hip.ptr(hyper), self.betas[0],
+                                             self.betas[1], self.eps, st), "adamw")
+        else:
+            _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
+                                         self.eps, self.step_count, st), "adamw")
         self.last_grad_norm = self._out2      # device tensor [norm, coef]; no host sync here
         # the kernel wrote the parameters behind torch's back: bump their version counters so every version-keyed cache (the
         # 16-bit / transposed GEMM weight copies of MViT._w and autograd._Ctx.wt) is refreshed on the next use

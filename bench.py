@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-record", action="store_true", help="train mode: skip the extra eval-forward timing")
+    ap.add_argument("--graph", action="store_true", help="loop mode: HIP.GRAPH_STEP (the train step as one replayed hipGraph)")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +123,7 @@ def main():
         opt = construct_optimizer(model, cfg)
         labels = torch.arange(args.batch, device=dev) % cfg.MODEL.NUM_CLASSES
         cfg.LOG_PERIOD = 10                                             # configs/Aicity/*.yaml value
+        cfg.HIP.GRAPH_STEP = bool(args.graph)
 
         class _Loader(list):
             pass
@@ -405,7 +407,8 @@ def main():
             line["parity_note"] = ("front end (gather + 8-bit INTER_LINEAR resize + normalise) is bit-exact vs oracle/window_oracle.py; "
                                    "cv2 is absent from this image, so that restatement of cv2.resize is itself unpinned (SURVEY 8f rank 1: parity unpinned)")
         if args.mode == "loop":
-            line["config"]["workload"] += " driven by engine.train_epoch (reference loop order, LOG_PERIOD 10, no per-iteration host sync)"
+            line["config"]["workload"] += " driven by engine.train_epoch (reference loop order, LOG_PERIOD 10, no per-iteration host sync%s)" % (
+                "; the step replayed as one hipGraph" if args.graph else "")
         if forward_rec is not None:
             line["forward"] = forward_rec
         line.update(extra_rooflines)

@@ -247,6 +247,11 @@ int mvit_mt_chunk_bytes(void);
 int mvit_grad_norm(const void* chunk_table, int nchunks, float max_norm, float* partials, float* out2, void* stream);
 int mvit_adamw_step(const void* chunk_table, int nchunks, const float* norm_coef, float lr, float beta1, float beta2,
                     float eps, int step, void* stream);
+/* The same with {lr, 1 - beta1^step, sqrt(1 - beta2^step)} read from 3 floats of device memory: nothing in the launch changes
+ * from iteration to iteration, so the whole train step can be captured in a hipGraph and replayed (the host refreshes the 3
+ * floats before each replay; tools/train_net.py:113-115 sets the LR every iteration). */
+int mvit_adamw_step_dev(const void* chunk_table, int nchunks, const float* norm_coef, const float* hyper, float beta1, float beta2,
+                        float eps, void* stream);
 
 /* Sliding-window front end (scripts/module_wrapper.py:304-370,384-397; scripts/utils.py:172-211): gather frame_length frames
  * per window by index from the decoded uint8 stream [N][H][W][3], resize to SxS with OpenCV's 8-bit INTER_LINEAR arithmetic

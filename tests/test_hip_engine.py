@@ -244,3 +244,44 @@ def test_multi_stream_train_step_matches_single_stream(tmp_path, precision):
             ref = res[0][1][k]
             tol = (2e-5 if precision == "fp32" else 2e-2) * max(1.0, ref.abs().max().item())
             assert (gr[k] - ref).abs().max().item() <= tol, (ns, k)
+
+
+def test_graphed_train_step_reproduces_the_eager_step(tmp_path):
+    """HIP.GRAPH_STEP: after two eager iterations engine.train_epoch captures the whole step (forward, loss, backward with its
+    side streams, clip + AdamW, top-k) in one hipGraph and replays it with the clip / labels / [lr, bias corrections] refreshed in
+    device memory.  Every reduction on the path is ordered, so the graphed run must reproduce the eager run BIT FOR BIT:
+    per-iteration losses and every parameter after 6 iterations with a different learning rate each."""
+    _, meta = load_golden("tiny_even")
+    ncls = 18
+    loader = _batches(meta, 6, 500, ncls)
+    res = {}
+    for graph in (False, True):
+        cfg, model = _make(meta, "bf16", str(tmp_path / ("g%d" % graph)))
+        cfg.HIP.GRAPH_STEP = graph
+        cfg.SOLVER.MAX_EPOCH, cfg.SOLVER.WARMUP_EPOCHS = 4, 2.0          # LR changes every iteration
+        opt = construct_optimizer(model, cfg)
+        tm = engine.TrainMeter(len(loader), cfg)
+        lines = []
+
+        class _Grab(logging.Handler):
+            def emit(self, record):
+                if record.getMessage().startswith("json_stats: "):
+                    lines.append(json.loads(record.getMessage().split("json_stats: ")[1]))
+        h = _Grab()
+        lg = logging.getLogger("aicity_action_amd.engine")
+        lg.addHandler(h)
+        old = lg.level
+        lg.setLevel(logging.INFO)
+        try:
+            engine.train_epoch(loader, model, opt, None, tm, 0, cfg)
+        finally:
+            lg.removeHandler(h)
+            lg.setLevel(old)
+        torch.cuda.synchronize()
+        if graph:
+            g = engine._graphed_step(model, opt, cfg, None)
+            assert g is not None and g.replays == 4 and opt.step_count == 6          # 2 eager + 4 replayed iterations
+        res[graph] = ([l["loss"] for l in lines if l["_type"] == "train_iter"], {k: p.detach().clone() for k, p in model.named_parameters()})
+    assert len(res[True][0]) == 6 and res[True][0] == res[False][0], (res[True][0], res[False][0])
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
