@@ -22,7 +22,9 @@ for m in train fwd; do
 done
 # HBM traffic of the attention kernels (PMC, separate passes)
 rm -rf gpurun_out/traffic
-MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd_hbm_traffic.json --mode fwd > /dev/null 2>&1
+MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd4_hbm_traffic.json --mode fwd > /dev/null 2>&1
+rm -rf gpurun_out/traffic
+MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd8_hbm_traffic.json --mode fwd --streams 1 > /dev/null 2>&1
 rm -rf gpurun_out/traffic
 MARKER=attn_bwd_delta tools/traffic.sh attn_bwd gpurun_out/${pre}_attn_bwd_hbm_traffic.json --mode train > /dev/null 2>&1
 rm -rf gpurun_out/traffic
