@@ -125,7 +125,8 @@ def _defaults():
         # run ahead of the GPU before it waits for a step's scalars (meters.DeviceScalarQueue).  GRAPH_STEP: engine.train_epoch
         # captures the whole train step in a hipGraph after two eager iterations and replays it (graph_step.py)
         "HIP": {"PRECISION": "bf16", "STREAMS": 2, "TRAIN_STREAMS": 1, "WGRAD_STREAM": True, "DDP_BUCKET_VIEW": True,
-                "DDP_STATIC_GRAPH": True, "DDP_BF16_GRADS": False, "STAT_QUEUE_DEPTH": 2, "GRAPH_STEP": False},
+                "DDP_STATIC_GRAPH": True, "DDP_BF16_GRADS": False, "STAT_QUEUE_DEPTH": 2, "GRAPH_STEP": False,
+                "REL_POS_BIAS": False},
     }
 
 

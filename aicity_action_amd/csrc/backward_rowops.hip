@@ -567,8 +567,27 @@ struct MtChunk { float* p; float* g; float* m; float* v; int n; float wd; };
 __global__ __launch_bounds__(256) void sqnorm_chunks_kernel(const MtChunk* __restrict__ ch, float* __restrict__ part) {
     __shared__ float red[4];
     const MtChunk c = ch[blockIdx.x];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < c.n; i += 256) { const float g = c.g[i]; s += g * g; }
+    // 16-byte loads, four independent partial sums per thread (the scalar form read 141 MB of gradients at 1.25 TB/s).  The
+    // element -> (thread, accumulator) map is the same whether or not the chunk is 16-byte aligned (gradients that are views into
+    // a DistributedDataParallel bucket need not be): the sum, and with it the clip factor, does not depend on where a gradient lives
+    const bool al = (reinterpret_cast<uintptr_t>(c.g) & 15) == 0;
+    const int n4 = c.n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(c.g);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (al) {
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 g = g4[i];
+            s0 += g.x * g.x; s1 += g.y * g.y; s2 += g.z * g.z; s3 += g.w * g.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float gx = c.g[4 * i], gy = c.g[4 * i + 1], gz = c.g[4 * i + 2], gw = c.g[4 * i + 3];
+            s0 += gx * gx; s1 += gy * gy; s2 += gz * gz; s3 += gw * gw;
+        }
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    for (int i = 4 * n4 + threadIdx.x; i < c.n; i += 256) { const float g = c.g[i]; s += g * g; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -605,16 +624,42 @@ __global__ __launch_bounds__(256) void adamw_chunks_kernel(const MtChunk* __rest
     // (bit test: the build uses -fno-honor-nans)
     if (coef_ptr && (((__float_as_uint(coef_ptr[0]) & 0x7f800000u) == 0x7f800000u) || ((__float_as_uint(coef) & 0x7f800000u) == 0x7f800000u)))
         return;
-    for (int i = threadIdx.x; i < c.n; i += 256) {
-        const float g = c.g[i] * coef;
-        float p = c.p[i] * (1.0f - lr * c.wd);
-        const float m = beta1 * c.m[i] + (1.0f - beta1) * g;
-        const float v = beta2 * c.v[i] + (1.0f - beta2) * g * g;
-        c.m[i] = m;
-        c.v[i] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        p -= (lr / bc1) * (m / denom);
-        c.p[i] = p;
+    // every operation spelled out with its rounding (no contraction left to the compiler): the 16-byte path and the scalar path
+    // below -- which one runs depends on the alignment of the gradient, e.g. a view into a DistributedDataParallel bucket -- must
+    // give the same bits
+    const float decay = __fsub_rn(1.0f, __fmul_rn(lr, c.wd)), step = __fdiv_rn(lr, bc1);
+    const float omb1 = __fsub_rn(1.0f, beta1), omb2 = __fsub_rn(1.0f, beta2);
+    auto upd = [&](float gi, float& p, float& m, float& v) {
+        const float g = __fmul_rn(gi, coef);
+        p = __fmul_rn(p, decay);
+        m = __fmaf_rn(beta1, m, __fmul_rn(omb1, g));
+        v = __fmaf_rn(beta2, v, __fmul_rn(__fmul_rn(omb2, g), g));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+        p = __fmaf_rn(-step, __fdiv_rn(m, denom), p);
+    };
+    // 16-byte accesses, two quads per thread in flight (same per-element arithmetic as the scalar tail below)
+    const bool al = ((reinterpret_cast<uintptr_t>(c.g) | reinterpret_cast<uintptr_t>(c.p) | reinterpret_cast<uintptr_t>(c.m) |
+                      reinterpret_cast<uintptr_t>(c.v)) & 15) == 0;
+    const int n4 = al ? (c.n >> 2) : 0;
+    float4* p4 = reinterpret_cast<float4*>(c.p);
+    float4* m4 = reinterpret_cast<float4*>(c.m);
+    float4* v4 = reinterpret_cast<float4*>(c.v);
+    const float4* g4 = reinterpret_cast<const float4*>(c.g);
+    for (int i = threadIdx.x; i < n4; i += 512) {
+        const int j = i + 256;
+        const bool two = j < n4;
+        const float4 ga = g4[i], gb = two ? g4[j] : ga;
+        float4 pa = p4[i], ma = m4[i], va = v4[i];
+        float4 pb = two ? p4[j] : pa, mb = two ? m4[j] : ma, vb = two ? v4[j] : va;
+        upd(ga.x, pa.x, ma.x, va.x); upd(ga.y, pa.y, ma.y, va.y); upd(ga.z, pa.z, ma.z, va.z); upd(ga.w, pa.w, ma.w, va.w);
+        upd(gb.x, pb.x, mb.x, vb.x); upd(gb.y, pb.y, mb.y, vb.y); upd(gb.z, pb.z, mb.z, vb.z); upd(gb.w, pb.w, mb.w, vb.w);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        if (two) { p4[j] = pb; m4[j] = mb; v4[j] = vb; }
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < c.n; i += 256) {
+        float p = c.p[i], m = c.m[i], v = c.v[i];
+        upd(c.g[i], p, m, v);
+        c.p[i] = p; c.m[i] = m; c.v[i] = v;
     }
 }
 

@@ -445,6 +445,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// First level of the two-level form (many slabs, few elements: e.g. the 96 -> 192 skip projection of block 1 leaves 784 slabs of
+// 18,624 floats, which 19 workgroups of the kernel above take 280 us to walk): workgroup (x, g) adds the `group` consecutive slabs
+// of group g in index order into the group's first slab, in place; wgrad_reduce_kernel then adds the group sums (slab step =
+// group).  The grouping depends only on (nch, element count), so the summation tree is fixed: still bit-reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(float* __restrict__ part, int nch, int group, int64_t stride, int64_t tot4) {
+    const int c0 = blockIdx.y * group, c1 = min(nch, c0 + group);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 256) {
+        float4 s = *reinterpret_cast<const float4*>(part + c0 * stride + 4 * i);
+        int c = c0 + 1;
+        for (; c + 3 < c1; c += 4) {      // four loads in flight, added in index order
+            const float4 t0 = *reinterpret_cast<const float4*>(part + c * stride + 4 * i);
+            const float4 t1 = *reinterpret_cast<const float4*>(part + (c + 1) * stride + 4 * i);
+            const float4 t2 = *reinterpret_cast<const float4*>(part + (c + 2) * stride + 4 * i);
+            const float4 t3 = *reinterpret_cast<const float4*>(part + (c + 3) * stride + 4 * i);
+            s.x += t0.x; s.y += t0.y; s.z += t0.z; s.w += t0.w;
+            s.x += t1.x; s.y += t1.y; s.z += t1.z; s.w += t1.w;
+            s.x += t2.x; s.y += t2.y; s.z += t2.z; s.w += t2.w;
+            s.x += t3.x; s.y += t3.y; s.z += t3.z; s.w += t3.w;
+        }
+        for (; c < c1; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(part + c * stride + 4 * i);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4*>(part + c0 * stride + 4 * i) = s;
+    }
+}
+
 // Launch plan shared by the entry point and the workspace query.
 struct WgradPlan { int path; int64_t nch; int mchunk; };     // path: 0 fp32 VALU, 1 big MFMA tile, 2 96x96 MFMA tile, < 0 error
 static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, bool scaled, int64_t M, int N, int K, int act_dtype) {
@@ -536,7 +563,20 @@ extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const
     if (part) {
         int64_t blocks = ((stride / 4) + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, (int)p.nch, stride, dW, db, (int64_t)N * K, N);
+        int nslab = (int)p.nch;
+        int64_t step = stride;
+        if (blocks < 256 && nslab >= 16) {          // few elements, many slabs: spread the slabs over the chip first
+            int groups = (int)((512 + blocks - 1) / blocks);
+            if (groups > nslab / 4) groups = nslab / 4;
+            const int group = (nslab + groups - 1) / groups;
+            groups = (nslab + group - 1) / group;
+            hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, st, part, nslab, group, stride,
+                               stride / 4);
+            MVIT_LAUNCH_CHECK();
+            nslab = groups;
+            step = stride * group;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, nslab, step, dW, db, (int64_t)N * K, N);
         MVIT_LAUNCH_CHECK();
     }
     return MVIT_OK;

@@ -104,6 +104,10 @@ class MViT(nn.Module):
         _unsupported(mv.NO_NORM_BEFORE_AVG, "MVIT.NO_NORM_BEFORE_AVG")
         _unsupported(mv.DROPOUT_RATE > 0.0, "MVIT.DROPOUT_RATE > 0")
         _unsupported(cfg.DETECTION.ENABLE, "DETECTION.ENABLE")
+        # hook, default off: this fork's attention is softmax(q k^T * scale) v with absolute separable position embeddings only
+        # (slowfast/models/attention.py:267-276 has no relative-position term), so turning a bias on would leave the reference's
+        # numbers; the place it would enter is the score tile of attn_fwd_pipe_kernel (one fp32 add per score before the row maximum)
+        _unsupported(bool(cfg.HIP.get("REL_POS_BIAS", False)), "HIP.REL_POS_BIAS (the reference model has no relative-position bias)")
         _unsupported(cfg.MODEL.USE_MULTI_HEAD, "MODEL.USE_MULTI_HEAD")
         _unsupported(cfg.CONTRA.ENABLE, "CONTRA.ENABLE")
         self.use_act_checkpoint = bool(cfg.MODEL.ACT_CHECKPOINT)     # video_model_builder.py:1036-1037

@@ -92,6 +92,11 @@ def test_cfg_cli_overrides_and_unsupported_branches():
     cfg2.MVIT.CLS_EMBED_ON = True
     with pytest.raises(NotImplementedError):
         MViT(cfg2)
+    cfg4 = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
+    assert cfg4.HIP.REL_POS_BIAS is False            # the hook north_star asks for: present, off, and refusing to be turned on
+    cfg4.HIP.REL_POS_BIAS = True
+    with pytest.raises(NotImplementedError):
+        MViT(cfg4)
     cfg3 = _cfg("MVITV2_FULL_B_16x4_CONV.yaml")
     cfg3.DATA.TEST_CROP_SIZE = 256
     with pytest.raises(AssertionError):

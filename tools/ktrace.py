@@ -22,5 +22,6 @@ for r in csv.DictReader(open(f)):
 rows = sorted(acc.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in acc.values())
 print("total %.3f ms/step over %d launch shapes" % (tot / steps / 1e6, len(rows)))
-for (name, gx, gy, gz, wx), (n, t) in rows[:60]:
+import os
+for (name, gx, gy, gz, wx), (n, t) in rows[:int(os.environ.get("KTRACE_ROWS", "60"))]:
     print("%-60s grid %9s %6s %3s wg %4s  calls/step %5.1f  avg %8.1f us  ms/step %7.3f" % (name, gx, gy, gz, wx, n / steps, t / n / 1e3, t / steps / 1e6))
