@@ -83,6 +83,8 @@ _SIGS = {
     "mvit_grad_norm": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p]),
     "mvit_adamw_step": (c_i, [c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
     "mvit_adamw_step_dev": (c_i, [c_p, c_i, c_p, c_p, c_f, c_f, c_f, c_p]),
+    "mvit_reduce_queue_begin": (c_i, []),
+    "mvit_reduce_queue_flush": (c_i, [c_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -20,6 +20,9 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+_REDUCE_QUEUE = os.environ.get("MVIT_REDUCE_QUEUE", "1") != "0"     # A/B switch: 0 = every reduction is its own launch
+
+
 def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev)
 
@@ -32,6 +35,7 @@ class _Ctx(object):
         self.L = model._lib()
         self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
         self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
+        self._red_keep = None   # workspaces pinned while a deferred-reduction queue is open (_BlockFn.backward)
         self._zpools = {}       # one zero pool per HIP stream (sub-batches of a step run on side streams)
         self._side_out = []
 
@@ -157,6 +161,8 @@ class _Ctx(object):
         dg = self.zeros(C)          # pre-zeroed pool slices + accumulate: the sliced partial reduction needs no memset
         db = self.zeros(C)
         ws = _ws(self.L.mvit_layernorm_bwd_workspace_bytes(C), x.device)
+        if self._red_keep is not None:      # a reduce queue is open: the partial table in ws is read at the flush
+            self._red_keep.append(ws)
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         if base is None and accumulate:
             base = dx
@@ -323,6 +329,13 @@ class _BlockFn(torch.autograd.Function):
         M, Mq = B * N, B * Lq
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         d_out = d_out.contiguous().view(Mq, Cout)
+        # the block's eight small parameter-gradient reductions (2 LayerNorms, 3 pooling convs x {LayerNorm, conv weights}) are
+        # queued by the library and go out as one launch at the end (mvit_reduce_queue_*); their partial tables stay alive in
+        # hx._red_keep until then
+        defer = _REDUCE_QUEUE
+        if defer:
+            _hip.check(L.mvit_reduce_queue_begin(), "reduce_queue_begin")
+            hx._red_keep = []
         # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
         g16, gs, grps = hx.scaled16(d_out, dp2, Lq)
         dW2, db2 = hx.wgrad(hid, g16, Cout, 4 * Cout, gs, grps)
@@ -359,8 +372,9 @@ class _BlockFn(torch.autograd.Function):
                    "attention_bwd")
         del d_o
         d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)
-        pws = _ws(max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1] if g.stride_q else 1),
-                      L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1])), dev)
+        pws_bytes = max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1] if g.stride_q else 1),
+                        L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1]))
+        pws = None if defer else _ws(pws_bytes, dev)      # queued reductions: one workspace per pooling conv, kept until the flush
         pool_grads = []
         bpools = [(1, dk, at.pool_k, at.norm_k, g.stride_kv[1]), (2, dv, at.pool_v, at.norm_v, g.stride_kv[1])]
         if g.kernel_q:
@@ -369,6 +383,9 @@ class _BlockFn(torch.autograd.Function):
             _hip.check(L.mvit_head_split_bwd(_hip.ptr(dq), _hip.ptr(d_qkv), 3 * Cout, 0, B, h, N, act, _st()), "head_split_bwd")
         for which, dbuf, conv, norm, stride in bpools:
             dconv = torch.empty_like(dbuf)
+            if defer:
+                pws = _ws(pws_bytes, dev)
+                hx._red_keep.append(pws)
             dw = hx.zeros(96, 1, 3, 3, 3)
             dgm = hx.zeros(96)
             dbt = hx.zeros(96)
@@ -395,6 +412,9 @@ class _BlockFn(torch.autograd.Function):
         else:
             d_x = d_r
         dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True)
+        if defer:
+            _hip.check(L.mvit_reduce_queue_flush(_st()), "reduce_queue_flush")
+            hx._red_keep = None
         grads = [dg1, dbe1, dWqkv, dbqkv, dWp, dbp] + pool_grads + [dg2, dbe2, dW1, db1, dW2, db2] + extra
         hx.join_side()
         return (d_x.view(B, N, Cin), None, None, None, None, None) + tuple(grads)

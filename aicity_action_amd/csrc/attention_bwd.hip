@@ -104,6 +104,12 @@ __device__ __forceinline__ bf16x4 b_tr16(uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+template <int OFF>
+__device__ __forceinline__ bf16x8 b_rd128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 __device__ __forceinline__ bf16x8 b_join(bf16x4 lo, bf16x4 hi) {
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
@@ -187,16 +193,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
     asm volatile("" : "+v"(lse), "+v"(dlt));
 
-    int koff[6];
-#pragma unroll
-    for (int ks = 0; ks < 6; ++ks) {
-        int p = 2 * ks + h + ((r >> 2) & 3);
-        p = p >= 12 ? p - 12 : p;
-        koff[ks] = p * 16;
-    }
+    // K / V row fragment of k-step ks: row r, 16-B chunk (2ks + h + rot(r)) mod 12 with rot <= 3: k-steps 0..3 never wrap (immediate
+    // offsets from one lane address), k-steps 4 and 5 each get their own
     // transposing reads on the rotation image: row 16*s16 + 4h + (i16>>2) (+8 for the second half), rotation h (+2)
     const int i16 = lane & 15, gi = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t ka0, ka4, ka5;
+    {
+        const int p0 = h + ((r >> 2) & 3);
+        const int p4 = p0 + 8 >= 12 ? p0 + 8 - 12 : p0 + 8, p5 = p0 + 10 >= 12 ? p0 + 10 - 12 : p0 + 10;
+        ka0 = lds0 + r * B_ROWB + p0 * 16;
+        ka4 = lds0 + r * B_ROWB + p4 * 16;
+        ka5 = lds0 + r * B_ROWB + p5 * 16;
+    }
     uint32_t t_lo[3], t_hi[3];
 #pragma unroll
     for (int db = 0; db < 3; ++db) {
@@ -220,8 +229,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nkt) dma((kt + 2) * B_T, stage == 0 ? 2 : stage - 1);
-        const char* sK = smem + stage * BQ_TILEB;
-        const char* sV = sK + B_T * B_ROWB;
         const uint32_t so = (uint32_t)(stage * BQ_TILEB);
         stage = stage == BQ_STAGES - 1 ? 0 : stage + 1;
 
@@ -230,15 +237,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 6; ++ks)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kb + r) * B_ROWB + koff[ks]);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (32 * kb + r) * B_ROWB + koff[ks]);
-                s[kb] = mfma16(kf, qf[ks], s[kb]);      // S^T  = K . Q^T
-                dp[kb] = mfma16(vf, dof[ks], dp[kb]);   // dP^T = V . dO^T
-            }
+        // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order).  Left to
+        // the compiler this phase was eleven rounds of {2 ds_read_b128; s_waitcnt lgkmcnt(0); 2 MFMA}: the LDS latency of every
+        // round exposed
+        bf16x8 kf[3][2], vf[3][2];
+        const uint32_t fa0 = ka0 + so, fa4 = ka4 + so, fa5 = ka5 + so;
+#define DQ_RD(SL, A, OFF) { kf[SL][0] = b_rd128<OFF>(A); vf[SL][0] = b_rd128<OFF + B_T * B_ROWB>(A); \
+                            kf[SL][1] = b_rd128<OFF + 32 * B_ROWB>(A); vf[SL][1] = b_rd128<OFF + B_T * B_ROWB + 32 * B_ROWB>(A); }
+#define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(kf[SL][0]), "+v"(vf[SL][0]), "+v"(kf[SL][1]), "+v"(vf[SL][1]) : "n"(N))
+#define DQ_MM(SL, KS) { s[0] = mfma16(kf[SL][0], qf[KS], s[0]); dp[0] = mfma16(vf[SL][0], dof[KS], dp[0]); \
+                        s[1] = mfma16(kf[SL][1], qf[KS], s[1]); dp[1] = mfma16(vf[SL][1], dof[KS], dp[1]); }
+        DQ_RD(0, fa0, 0) DQ_RD(1, fa0, 32)
+        DQ_WAIT(0, 4);
+        DQ_RD(2, fa0, 64)
+        DQ_MM(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        DQ_WAIT(1, 4);
+        DQ_RD(0, fa0, 96)
+        DQ_MM(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        DQ_WAIT(2, 4);
+        DQ_RD(1, fa4, 0)
+        DQ_MM(2, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        DQ_WAIT(0, 4);
+        DQ_RD(2, fa5, 0)
+        DQ_MM(0, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        DQ_WAIT(1, 4);
+        DQ_MM(1, 4)
+        __builtin_amdgcn_sched_barrier(0);
         // K^T fragments of the first two 16-key steps: requested now, they land under the dS arithmetic
         bf16x4 ta[12];
 #define TRQ(A, S16) \
@@ -249,6 +277,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         A[8] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[1] + so); A[9] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[1] + so); \
         A[10] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[2] + so); A[11] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[2] + so);
         TRQ(ta, 0)
+        DQ_WAIT(2, 12);       // the twelve transposing reads just issued stay in flight under these MFMAs and the dS arithmetic
+        DQ_MM(2, 5)
+        __builtin_amdgcn_sched_barrier(0);
+#undef DQ_RD
+#undef DQ_WAIT
+#undef DQ_MM
         const int kbase = kt * B_T;
         const bool tail = kbase + B_T > Lk;
         bf16x8 dsf[4];

@@ -112,16 +112,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 __device__ float g_red_scratch[RED_SLOTS][RED_MAXSLICE][RED_MAXW];
 __device__ unsigned g_red_ticket[RED_SLOTS][RED_MAXW / 64];
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
-                                                              float* __restrict__ out_a, float* __restrict__ out_b,
-                                                              int split, int accumulate, int slot) {
-    __shared__ float red[4][64];
-    __shared__ unsigned last;
+// one (column block bx, row slice by of nsl) unit of the reduction described above
+__device__ __forceinline__ void reduce_partials_body(const float* __restrict__ part, int nparts, int width, float* __restrict__ out_a,
+                                                     float* __restrict__ out_b, int split, int accumulate, int slot, int bx, int by,
+                                                     int nsl, float (*red)[64], unsigned* last) {
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + col;
-    const int nsl = gridDim.y;
+    const int j = bx * 64 + col;
     const int per = (nparts + nsl - 1) / nsl;
-    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
+    const int b0 = by * per, b1 = min(nparts, b0 + per);
     float s = 0.f;
     if (j < width)
         for (int b = b0 + sl; b < b1; b += 4) s += part[(int64_t)b * width + j];
@@ -139,41 +137,107 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
             return;
         }
         // write-through (sc1) store: visible to every CU without a release fence once this wave's vmcnt has drained
-        __hip_atomic_store(&g_red_scratch[slot][blockIdx.y][j < RED_MAXW ? j : 0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_red_scratch[slot][by][j < RED_MAXW ? j : 0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // publish (cdna guide G16, sc1 form): the storing wave drains its stores, the workgroup meets, ONE lane takes a ticket; the
     // last arriver reads the parked rows with sc1 loads (L1 bypassed: no acquire fence needed)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&g_red_ticket[slot][blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (unsigned)nsl - 1u) ? 1u : 0u;
-        if (last) __hip_atomic_store(&g_red_ticket[slot][blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        const unsigned t = __hip_atomic_fetch_add(&g_red_ticket[slot][bx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *last = (t == (unsigned)nsl - 1u) ? 1u : 0u;
+        if (*last) __hip_atomic_store(&g_red_ticket[slot][bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     __syncthreads();
-    if (!last || sl != 0 || j >= width) return;
+    if (!*last || sl != 0 || j >= width) return;
     float tot = 0.f;
     for (int y = 0; y < nsl; ++y) tot += __hip_atomic_load(&g_red_scratch[slot][y][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* o = (j < split) ? out_a + j : out_b + (j - split);
     *o = accumulate ? *o + tot : tot;
 }
 
-// shared by every file of the library that reduces a partial table (declared in common.h)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int width,
+                                                              float* __restrict__ out_a, float* __restrict__ out_b,
+                                                              int split, int accumulate, int slot) {
+    __shared__ float red[4][64];
+    __shared__ unsigned last;
+    reduce_partials_body(part, nparts, width, out_a, out_b, split, accumulate, slot, blockIdx.x, blockIdx.y, gridDim.y, red, &last);
+}
+
+// A batch of such reductions in ONE launch (descriptors by value in the kernel arguments: no upload): the block backward queues
+// its eight small reductions (two LayerNorms, three pooling convs x {LayerNorm, conv weights}) and flushes them together --
+// 16 launches per step instead of 131, each of which cost ~11 us for a few microseconds of work.
+#define RED_QMAX 16
+struct RedDesc { const float* part; float* out_a; float* out_b; int nparts, width, split, accumulate, slot, nsl, first; };
+struct RedBatch { RedDesc d[RED_QMAX]; int n; };
+
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const RedBatch b) {
+    __shared__ float red[4][64];
+    __shared__ unsigned last;
+    int i = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.n; ++k) i = ((int)blockIdx.x >= b.d[k].first) ? k : i;
+    const RedDesc& d = b.d[i];
+    const int u = blockIdx.x - d.first;           // unit = column block * nsl + slice
+    reduce_partials_body(d.part, d.nparts, d.width, d.out_a, d.out_b, d.split, d.accumulate, d.slot, u / d.nsl, u % d.nsl, d.nsl, red, &last);
+}
+
+static RedBatch g_red_queue;
+static bool g_red_queue_on = false;
+static int g_red_units = 0;
+static unsigned g_red_next_slot = 0;
+
+static int red_flush(hipStream_t st) {
+    if (g_red_queue.n > 0) {
+        hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((unsigned)g_red_units), dim3(256), 0, st, g_red_queue);
+        g_red_queue.n = 0;
+        g_red_units = 0;
+        MVIT_LAUNCH_CHECK();
+    }
+    return MVIT_OK;
+}
+
+// Deferred mode (see include/mvit_hip.h): between _begin and _flush the LayerNorm / pooling-conv backward entry points queue their
+// parameter-gradient reductions instead of launching them; _flush(stream) launches the batch on `stream`, which must be ordered
+// after every producer.  The partial tables live in the callers' workspaces: those must stay untouched until the flush.
+extern "C" int mvit_reduce_queue_begin(void) {
+    g_red_queue.n = 0;
+    g_red_units = 0;
+    g_red_queue_on = true;
+    return MVIT_OK;
+}
+extern "C" int mvit_reduce_queue_flush(void* stream) {
+    g_red_queue_on = false;
+    return red_flush(as_stream(stream));
+}
+
+// shared by every file of the library that reduces a partial table (declared in common.h); defer_ok: this reduction may wait in
+// the queue (its partial table is not reused by the caller before the flush)
 int mvit_internal_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
-                                  hipStream_t st) {
-    static unsigned next_slot = 0;
+                                  hipStream_t st, int defer_ok) {
     if (width > RED_MAXW) return MVIT_EUNSUPPORTED;
     int slices = nparts / 64;
     slices = slices < 1 ? 1 : (slices > RED_MAXSLICE ? RED_MAXSLICE : slices);
-    const int slot = (int)(next_slot++ % RED_SLOTS);
+    const int slot = (int)(g_red_next_slot++ % RED_SLOTS);
+    if (defer_ok && g_red_queue_on) {
+        if (g_red_queue.n == RED_QMAX) {            // full: what is queued goes out now, on this stream
+            const int rc = red_flush(st);
+            if (rc != MVIT_OK) return rc;
+        }
+        RedDesc& d = g_red_queue.d[g_red_queue.n++];
+        d.part = part; d.out_a = out_a; d.out_b = out_b; d.nparts = nparts; d.width = width; d.split = split;
+        d.accumulate = accumulate; d.slot = slot; d.nsl = slices; d.first = g_red_units;
+        g_red_units += ((width + 63) / 64) * slices;
+        return MVIT_OK;
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
                        accumulate, slot);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
 static int launch_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
-                                  hipStream_t st) {
-    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st);
+                                  hipStream_t st, int defer_ok = 0) {
+    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st, defer_ok);
 }
 
 #define LN_BWD_MAXBLK 1024     // 4 workgroups per CU: the kernel is HBM-bound
@@ -188,7 +252,7 @@ static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int
     hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
                        base, dx, ws, rows, eps);
     MVIT_LAUNCH_CHECK();
-    return launch_reduce_partials(ws, (int)blocks, 2 * C, dgamma, dbeta, C, acc_param, st);
+    return launch_reduce_partials(ws, (int)blocks, 2 * C, dgamma, dbeta, C, acc_param, st, 1);
 }
 
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).

@@ -173,4 +173,4 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 // deterministic column sums of a [nparts][width] fp32 partial table (backward_rowops.hip)
 int mvit_internal_reduce_partials(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
-                                  hipStream_t st);
+                                  hipStream_t st, int defer_ok = 0);

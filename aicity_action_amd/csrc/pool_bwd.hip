@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const TA* __restrict__
 // out[j] (+)= sum_b part[b][j], width columns; columns [0,split) -> out_a, rest -> out_b: the library's deterministic
 // single-launch column reduce (backward_rowops.hip: row slices parked in scratch, the last-arriving slice adds them in order)
 static int launch_pool_reduce(const float* part, int nparts, int width, float* out_a, float* out_b, int split, int accumulate,
-                              hipStream_t st) {
-    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st);
+                              hipStream_t st, int defer_ok = 0) {
+    return mvit_internal_reduce_partials(part, nparts, width, out_a, out_b, split, accumulate, st, defer_ok);
 }
 
 template <typename TA>
@@ -544,7 +544,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         MVIT_LAUNCH_CHECK();                                                                                               \
         ss = side_stream_for_current_device();                                                                             \
         if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
-        { const int rr_ = launch_pool_reduce(workspace, (int)bs, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
+        { const int rr_ = launch_pool_reduce(workspace, (int)bs, 192, dgamma, dbeta, 96, accumulate_param, st, 1); if (rr_ != MVIT_OK) return rr_; } \
     } else if (tiled) {                                                                                                    \
         const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
                                                           H, W, stride_hw, eps, act_dtype, st);                            \
@@ -567,12 +567,12 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
                                                       act_dtype, sw);                                                      \
         if (wr < 0) return wr;                                                                                             \
-        { const int rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, sw); if (rr_ != MVIT_OK) return rr_; }       \
+        { const int rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, sw, xhat != nullptr); if (rr_ != MVIT_OK) return rr_; } \
     } else {                                                                                                               \
         hipLaunchKernelGGL((pool_wgrad_kernel<TA>), dim3((unsigned)b3), dim3(1024), 0, sw, (const TA*)qkv, ld, chan_off,     \
                            (const TA*)dconv, wpart, B, heads, T, H, W, Ho, Wo, stride_hw);                                 \
         MVIT_LAUNCH_CHECK();                                                                                               \
-        { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, sw); if (rr_ != MVIT_OK) return rr_; }  \
+        { const int rr_ = launch_pool_reduce(wpart, (int)b3, 2592, dw, dw, 2592, 1, sw, xhat != nullptr); if (rr_ != MVIT_OK) return rr_; } \
     }                                                                                                                      \
     if (stride_hw == 1 && dgrad_tiled) {    /* stride 1: the data gradient IS the tiled convolution with mirrored taps */      \
         const int dr = mvit_internal_pool_dgrad_tiled(dconv, w, dqkv, ld, chan_off, B, heads, T, H, W, act_dtype, st);      \

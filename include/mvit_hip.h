@@ -276,6 +276,17 @@ void* mvit_side_stream(void);
 int mvit_side_fork(void* stream);
 int mvit_side_join(void* stream);
 
+/* Deferred parameter-gradient reductions.  mvit_layernorm_bwd2 and mvit_pool_conv_ln_bwd_saved each end in small column-sum
+ * launches over a partial table in their workspace (d_gamma / d_beta, conv d_w): eight per block backward, ~11 us apiece for a few
+ * microseconds of work.  Between mvit_reduce_queue_begin() and mvit_reduce_queue_flush(stream) those launches are queued instead
+ * (up to 16; a full queue flushes itself) and go out as ONE launch on `stream`, which must be ordered after every producer.
+ * Contract while a queue is open: every workspace handed to those two entry points stays untouched (not freed, not passed to
+ * another call) until the flush -- the partial tables live there.  The outputs (d_gamma, d_beta, d_w) are complete after the flush.
+ * Same threading contract as the side stream (one queue per process, main thread).  The sums are bit-identical to the immediate
+ * form: the same units of work in the same order, only launched together. */
+int mvit_reduce_queue_begin(void);
+int mvit_reduce_queue_flush(void* stream);
+
 /* Query path of blocks WITHOUT a pooling conv (MVIT.Q_POOL_ALL off -> pool_q is None, attention.py:14-15,131-134,239-246):
  * out[b][g][n][:] = qkv[b][n][chan_off + g*96 : +96] (head split only, no LayerNorm); _bwd copies dout back into the slice of the
  * fused gradient buffer. */
