@@ -49,6 +49,7 @@ _SIGS = {
     "mvit_layernorm_bwd_workspace_bytes": (c_l, [c_i]),
     "mvit_layernorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p]),
     "mvit_layernorm_bwd2": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p]),
+    "mvit_layernorm_bwd3": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p, c_l, c_p]),
     "mvit_gelu_fwd": (c_i, [c_p, c_p, c_l, c_i, c_p]),
     "mvit_gelu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     "mvit_linear_gelu_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),

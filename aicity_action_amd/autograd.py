@@ -21,6 +21,7 @@ def _st():
 
 
 _REDUCE_QUEUE = os.environ.get("MVIT_REDUCE_QUEUE", "1") != "0"     # A/B switch: 0 = every reduction is its own launch
+_LN_EMIT16 = os.environ.get("MVIT_LN_EMIT16", "1") != "0"           # A/B switch: 0 = separate cast passes over the stream gradient
 
 
 def _ws(nbytes, dev):
@@ -36,6 +37,8 @@ class _Ctx(object):
         self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
         self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
         self._red_keep = None   # workspaces pinned while a deferred-reduction queue is open (_BlockFn.backward)
+        self._last_block = None  # (index, dp2, output data_ptr) of the block that ran last in this chain (forward)
+        self._g16_stash = None   # (data_ptr of a stream gradient, its 16-bit scaled copy) handed from one block backward to the next
         self._zpools = {}       # one zero pool per HIP stream (sub-batches of a step run on side streams)
         self._side_out = []
 
@@ -155,8 +158,10 @@ class _Ctx(object):
                                              norm.eps, self.act, _st()), "ln")
         return y
 
-    def ln_bwd(self, x, norm, dy, dx, accumulate, rows_per_dy=1, dy_scale=1.0, base=None):
-        """dx = [base | dx if accumulate | 0] + LN-backward(dy); returns (dgamma, dbeta)."""
+    def ln_bwd(self, x, norm, dy, dx, accumulate, rows_per_dy=1, dy_scale=1.0, base=None, emit16=None):
+        """dx = [base | dx if accumulate | 0] + LN-backward(dy); returns (dgamma, dbeta).  emit16 = (row_scale | None, rows_per_scale):
+        also returns dx * row_scale as the 16-bit operand of the GEMMs that consume it next (None on the fp32 path) -- the copy
+        mvit_cast_rows_f32_to_bf16 would make, written by the same kernel instead of a second pass over dx."""
         rows, C = x.shape
         dg = self.zeros(C)          # pre-zeroed pool slices + accumulate: the sliced partial reduction needs no memset
         db = self.zeros(C)
@@ -166,9 +171,16 @@ class _Ctx(object):
         ddt = _hip.F32 if dy.dtype == torch.float32 else _hip.BF16
         if base is None and accumulate:
             base = dx
-        _hip.check(self.L.mvit_layernorm_bwd2(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
+        out16, sc16, rps16 = None, None, 0
+        if emit16 is not None and self.act != _hip.F32 and _LN_EMIT16:
+            out16 = torch.empty(dx.shape, dtype=self.adt, device=dx.device)
+            sc16, rps16 = emit16
+        _hip.check(self.L.mvit_layernorm_bwd3(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
                                               _hip.ptr(base), _hip.ptr(dx), _hip.ptr(dg), _hip.ptr(db), 1, _hip.ptr(ws),
-                                              rows, C, norm.eps, _st()), "ln_bwd")
+                                              rows, C, norm.eps, _hip.ptr(out16), _hip.ptr(sc16), rps16 if sc16 is not None else 0,
+                                              _st()), "ln_bwd")
+        if emit16 is not None:
+            return dg, db, out16
         return dg, db
 
 
@@ -226,6 +238,11 @@ class _BlockFn(torch.autograd.Function):
         out, saved, pool_saved, mlp_dsave = _BlockFn._run_forward(x, hx, g, blk, dp1, dp2)
         ctx.hx, ctx.g, ctx.blk, ctx.addq = hx, g, blk, 1 if hx.m.use_query_residual_pool else 0
         ctx.mlp_dsave = mlp_dsave
+        # the block upstream in this chain and its MLP drop-path draw: this block's backward hands that block its incoming gradient
+        # already cast (see backward)
+        prev = hx._last_block
+        ctx.prev_dp2 = (prev[1],) if (prev is not None and prev[0] == g.index - 1 and prev[2] == x.data_ptr()) else None
+        hx._last_block = (g.index, dp2, out.data_ptr())
         if hx.m.use_act_checkpoint:
             ctx.saved, ctx.pool_saved = None, None
             ctx.recompute = (x, dp1, dp2)
@@ -337,7 +354,13 @@ class _BlockFn(torch.autograd.Function):
             _hip.check(L.mvit_reduce_queue_begin(), "reduce_queue_begin")
             hx._red_keep = []
         # ---- MLP branch: out = y + dp2 * (fc2(gelu(fc1(LN2(y))))) ------------------------------------------
-        g16, gs, grps = hx.scaled16(d_out, dp2, Lq)
+        stash = hx._g16_stash
+        hx._g16_stash = None
+        if stash is not None and stash[0] == d_out.data_ptr() and stash[1].shape == d_out.shape:
+            g16, gs, grps = stash[1], None, 0       # written by the downstream block's LayerNorm backward, drop-path factor applied
+        else:
+            g16, gs, grps = hx.scaled16(d_out, dp2, Lq)
+        del stash
         dW2, db2 = hx.wgrad(hid, g16, Cout, 4 * Cout, gs, grps)
         if act == _hip.BF16:      # fc2 data gradient and the GELU backward in one GEMM pass
             w2t = hx.wt(blk.mlp.fc2.weight)
@@ -356,10 +379,15 @@ class _BlockFn(torch.autograd.Function):
         d_vn = hx.linear(d_pre, hx.wt(blk.mlp.fc1.weight), None, adt)
         del d_pre
         d_y = torch.empty_like(d_out)
-        dg2, dbe2 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, False, base=d_out)       # d_y = d_out + LN2-backward (no clone)
+        # d_y = d_out + LN2-backward (no clone); the same kernel writes d_y * dp1 as the 16-bit operand of the proj GEMMs
+        dg2, dbe2, y16 = hx.ln_bwd(y, blk.norm2, d_vn, d_y, False, base=d_out, emit16=(dp1, Lq))
         del d_vn
         # ---- attention branch: y = r + dp1 * proj(o) ------------------------------------------------------
-        g16, gs, grps = hx.scaled16(d_y, dp1, Lq)
+        if y16 is not None:
+            g16, gs, grps = y16, None, 0
+        else:
+            g16, gs, grps = hx.scaled16(d_y, dp1, Lq)
+        del y16
         dWp, dbp = hx.wgrad(o, g16, Cout, Cout, gs, grps)
         d_o = hx.linear(g16, hx.wt(at.proj.weight), None, adt, row_scale=gs, rps=grps)
         del g16
@@ -411,7 +439,12 @@ class _BlockFn(torch.autograd.Function):
             extra = [dWm, dbm]
         else:
             d_x = d_r
-        dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True)
+        if ctx.prev_dp2 is not None:      # d_x is the upstream block's incoming gradient: cast it for that block's fc2 GEMMs right here
+            dg1, dbe1, x16 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True, emit16=(ctx.prev_dp2[0], N))
+            if x16 is not None:
+                hx._g16_stash = (d_x.data_ptr(), x16)
+        else:
+            dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True)
         if defer:
             _hip.check(L.mvit_reduce_queue_flush(_st()), "reduce_queue_flush")
             hx._red_keep = None

@@ -19,7 +19,8 @@ template <int C, typename TDY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const TDY* __restrict__ dy, int64_t rows_per_dy, float dy_scale,
                                                      const float* base, float* dx, float* __restrict__ part,
-                                                     int64_t rows, float eps) {
+                                                     int64_t rows, float eps, bf16_t* __restrict__ dx16,
+                                                     const float* __restrict__ scale16, int64_t rps16) {
     constexpr int LPR = C / 12;
     constexpr int RPB = 256 / LPR;
     __shared__ float red[RPB][2 * C];
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         c1 = gsum<LPR>(c1) * (1.0f / C);
         c2 = gsum<LPR>(c2) * (1.0f / C);
         if (ok) {
+            const float sc16 = (dx16 && scale16) ? scale16[r / rps16] : 1.0f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 float* p = dx + r * C + 4 * (lir + LPR * i);
@@ -82,6 +84,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                     o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
                 }
                 store4(p, o);
+                if (dx16) {          // the same gradient as the 16-bit operand of the next GEMMs (what mvit_cast_rows_f32_to_bf16 would write)
+                    o.x *= sc16; o.y *= sc16; o.z *= sc16; o.w *= sc16;
+                    store4(dx16 + r * C + 4 * (lir + LPR * i), o);
+                }
             }
         }
     }
@@ -245,14 +251,43 @@ extern "C" int64_t mvit_layernorm_bwd_workspace_bytes(int C) { return (int64_t)L
 
 template <int C, typename TDY>
 static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int64_t rpd, float dys, const float* base, float* dx,
-                         float* dgamma, float* dbeta, int acc_param, float* ws, int64_t rows, float eps, hipStream_t st) {
+                         float* dgamma, float* dbeta, int acc_param, float* ws, int64_t rows, float eps, hipStream_t st,
+                         void* dx16, const float* scale16, int64_t rps16) {
     constexpr int RPB = 256 / (C / 12);
     int64_t blocks = (rows + RPB - 1) / RPB;
     if (blocks > LN_BWD_MAXBLK) blocks = LN_BWD_MAXBLK;
     hipLaunchKernelGGL((ln_bwd_kernel<C, TDY>), dim3((unsigned)blocks), dim3(256), 0, st, x, gamma, (const TDY*)dy, rpd, dys,
-                       base, dx, ws, rows, eps);
+                       base, dx, ws, rows, eps, (bf16_t*)dx16, scale16, rps16);
     MVIT_LAUNCH_CHECK();
     return launch_reduce_partials(ws, (int)blocks, 2 * C, dgamma, dbeta, C, acc_param, st, 1);
+}
+
+// dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
+// dx = (dx_base ? dx_base : 0) + LayerNorm-backward(dy); dx_base may alias dx (in-place accumulate) or be a different buffer
+// (the block backward adds the norm-2 branch onto the incoming stream gradient without cloning it first).
+extern "C" int mvit_layernorm_bwd3(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+                                   float dy_scale, const float* dx_base, float* dx, float* dgamma, float* dbeta,
+                                   int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* dx16,
+                                   const float* dx16_row_scale, int64_t dx16_rows_per_scale, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || rows_per_dy <= 0) return MVIT_EINVAL;
+    if (dx16 && dx16_row_scale && dx16_rows_per_scale <= 0) return MVIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+#define LNB(CC)                                                                                                      \
+    case CC:                                                                                                         \
+        if (dy_dtype == MVIT_F32)                                                                                    \
+            return launch_ln_bwd<CC, float>(x, gamma, dy, rows_per_dy, dy_scale, dx_base, dx, dgamma, dbeta,          \
+                                            accumulate_param, workspace, rows, eps, st, dx16, dx16_row_scale,        \
+                                            dx16_rows_per_scale);                                                    \
+        if (dy_dtype == MVIT_BF16 && rows_per_dy == 1)                                                               \
+            return launch_ln_bwd<CC, bf16_t>(x, gamma, dy, 1, dy_scale, dx_base, dx, dgamma, dbeta,                   \
+                                             accumulate_param, workspace, rows, eps, st, dx16, dx16_row_scale,       \
+                                             dx16_rows_per_scale);                                                   \
+        return MVIT_EDTYPE;
+    switch (C) {
+        LNB(96) LNB(192) LNB(384) LNB(768)
+        default: return MVIT_EUNSUPPORTED;
+    }
+#undef LNB
 }
 
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
@@ -261,22 +296,8 @@ static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int
 extern "C" int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
                                    float dy_scale, const float* dx_base, float* dx, float* dgamma, float* dbeta,
                                    int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
-    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || rows_per_dy <= 0) return MVIT_EINVAL;
-    hipStream_t st = as_stream(stream);
-#define LNB(CC)                                                                                                      \
-    case CC:                                                                                                         \
-        if (dy_dtype == MVIT_F32)                                                                                    \
-            return launch_ln_bwd<CC, float>(x, gamma, dy, rows_per_dy, dy_scale, dx_base, dx, dgamma, dbeta,          \
-                                            accumulate_param, workspace, rows, eps, st);                             \
-        if (dy_dtype == MVIT_BF16 && rows_per_dy == 1)                                                               \
-            return launch_ln_bwd<CC, bf16_t>(x, gamma, dy, 1, dy_scale, dx_base, dx, dgamma, dbeta,                   \
-                                             accumulate_param, workspace, rows, eps, st);                            \
-        return MVIT_EDTYPE;
-    switch (C) {
-        LNB(96) LNB(192) LNB(384) LNB(768)
-        default: return MVIT_EUNSUPPORTED;
-    }
-#undef LNB
+    return mvit_layernorm_bwd3(x, gamma, dy, dy_dtype, rows_per_dy, dy_scale, dx_base, dx, dgamma, dbeta, accumulate_param, workspace,
+                               rows, C, eps, nullptr, nullptr, 0, stream);
 }
 
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).

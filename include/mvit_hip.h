@@ -127,6 +127,13 @@ int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int d
 int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
                         const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
                         int64_t rows, int C, float eps, void* stream);
+/* Same, and the resulting dx also leaves as the 16-bit operand of the GEMMs that consume it next: dx16[r][:] = (16-bit)(dx[r][:] *
+ * (dx16_row_scale ? dx16_row_scale[r / dx16_rows_per_scale] : 1)) -- bit for bit what mvit_cast_rows_f32_to_bf16 would make of dx
+ * (the residual-stream gradient times the next branch's drop-path factor), without reading dx back.  dx16 == NULL: as _bwd2. */
+int mvit_layernorm_bwd3(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
+                        const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
+                        int64_t rows, int C, float eps, void* dx16, const float* dx16_row_scale, int64_t dx16_rows_per_scale,
+                        void* stream);
 
 /* erf-GELU as separate elementwise passes (training keeps the pre-activation; slowfast/models/common.py:28). */
 int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
