@@ -311,7 +311,7 @@ class _BlockFn(torch.autograd.Function):
             # `pre` holds GELU'(fc1 output) when both MLP GEMMs fit the 128x192 kernels (the backward then only multiplies), else the
             # pre-activation itself
             n1, k1 = w1.shape
-            mlp_dsave = (n1 % 192 == 0 and k1 % 64 == 0 and os.environ.get("MVIT_GELU_DSAVE", "1") != "0")
+            mlp_dsave = (n1 % 192 == 0 and (k1 % 64 == 0 or (k1 % 64 == 32 and k1 >= 64)) and os.environ.get("MVIT_GELU_DSAVE", "1") != "0")
             fc1 = L.mvit_linear_gelu_fwd_dsave if mlp_dsave else L.mvit_linear_gelu_fwd
             _hip.check(fc1(_hip.ptr(vn), k1, _hip.ptr(w1), _hip.ptr(blk.mlp.fc1.bias), _hip.ptr(pre), _hip.ptr(hid), Mq, n1, k1, act,
                            _st()), "fc1+gelu")

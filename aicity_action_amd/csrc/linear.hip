@@ -501,6 +501,7 @@ static int launch_linear_dma(const void* a, int64_t lda, const void* w, const fl
 #define G_PANEL_B (G_BN * G_ROWB)     // 24576
 #define G_BUF (G_PANEL_A + G_PANEL_B) // 40960
 #define G_SMEM (2 * G_BUF)            // 81920
+#define G_KOK(K) ((K) % G_BK == 0 || ((K) % G_BK == 32 && (K) >= G_BK))      // K the 128x192 kernels cover (see ktail)
 
 // LDS fragment reads of the persistent kernel are inline asm: the compiler cannot tell a ds_read from the LDS-DMA
 // writes still in flight for the next slab and (depending on how it peels the loop) puts s_waitcnt vmcnt(0) in front of
@@ -602,12 +603,16 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         lds_w[ks] = lds0 + G_PANEL_A + (96 * wn + r) * G_ROWB + fo;     // weight rows (MFMA A operand)
     }
 
-    const int nk = K / G_BK;
+    // K = 64 j + 32 (the 96-wide layers of block 0): the last slab is loaded from column K - 64, so nothing is read past a row,
+    // and its first two k-steps -- columns the previous slab already covered -- are multiplied with zeroed token fragments
+    const int nk = (K + G_BK - 1) / G_BK;
+    const bool ktail = (K & (G_BK - 1)) != 0;
     dma(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
         __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other buffer
-        if (kt + 1 < nk) dma((kt + 1) * G_BK, (kt + 1) & 1);
+        if (kt + 1 < nk) dma((ktail && kt + 2 == nk) ? K - G_BK : (kt + 1) * G_BK, (kt + 1) & 1);
+        const bool half = ktail && kt + 1 == nk;
         const uint32_t bo = (kt & 1) ? G_BUF : 0;
         bf16x8 xf[4][2], wf[4][3];
 #define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
@@ -617,10 +622,12 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                  acc[mb][nb] = mfma16(wf[KS][nb], xf[KS][mb], acc[mb][nb]);
         RD(0) RD(1)
         lds_wait5<5>(xf[0][0], xf[0][1], wf[0][0], wf[0][1], wf[0][2]);
+        if (half) { xf[0][0] = bf16x8{}; xf[0][1] = bf16x8{}; }
         RD(2)
         MM(0)
         __builtin_amdgcn_sched_barrier(0);
         lds_wait5<5>(xf[1][0], xf[1][1], wf[1][0], wf[1][1], wf[1][2]);
+        if (half) { xf[1][0] = bf16x8{}; xf[1][1] = bf16x8{}; }
         RD(3)
         MM(1)
         __builtin_amdgcn_sched_barrier(0);
@@ -852,7 +859,8 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
         lds_x[ks] = lds0 + (64 * wm + r) * G_ROWB + fo;                 // token rows  (MFMA B operand)
         lds_w[ks] = lds0 + G_PANEL_A + (96 * wn + r) * G_ROWB + fo;     // weight rows (MFMA A operand)
     }
-    const int nk = K / G_BK;
+    const int nk = (K + G_BK - 1) / G_BK;           // K = 64 j + 32: see linear_big_kernel
+    const bool ktail = (K & (G_BK - 1)) != 0;
 
     // per-tile DMA sources
     const bf16_t* a_src[4];
@@ -917,8 +925,9 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
             if (kt == 0 && trail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab s have landed
             __builtin_amdgcn_s_barrier();                          // everyone's have; the other buffer is free
-            if (kt + 1 < nk) dma((kt + 1) * G_BK, (s + 1) & 1);
+            if (kt + 1 < nk) dma((ktail && kt + 2 == nk) ? K - G_BK : (kt + 1) * G_BK, (s + 1) & 1);
             else if (has_next) { setup(t_next); dma(0, (s + 1) & 1); }
+            const bool half = ktail && kt + 1 == nk;
             const uint32_t bo = (s & 1) ? G_BUF : 0;
             bf16x8 xf[4][2], wf[4][3];
 #define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
@@ -929,10 +938,12 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
             // fragment pipeline: two k-steps of reads in flight ahead of the MFMAs (LDS returns in order)
             RD(0) RD(1)
             lds_wait5<5>(xf[0][0], xf[0][1], wf[0][0], wf[0][1], wf[0][2]);
+            if (half) { xf[0][0] = bf16x8{}; xf[0][1] = bf16x8{}; }
             RD(2)
             MM(0)
             __builtin_amdgcn_sched_barrier(0);
             lds_wait5<5>(xf[1][0], xf[1][1], wf[1][0], wf[1][1], wf[1][2]);
+            if (half) { xf[1][0] = bf16x8{}; xf[1][1] = bf16x8{}; }
             RD(3)
             MM(1)
             __builtin_amdgcn_sched_barrier(0);
@@ -1151,13 +1162,14 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         return MVIT_OK;
     }
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
-    if (K % LBK || N % LBN || (lda & 7) || (ldy & 3) || ((epilogue & MVIT_EPI_RESIDUAL) && (ldr & 3)))
+    const bool big_shape = a_dtype == MVIT_BF16 && N % G_BN == 0 && G_KOK(K);      // the 128x192 kernels take any such K
+    if ((K % LBK && !big_shape) || N % LBN || (lda & 7) || (ldy & 3) || ((epilogue & MVIT_EPI_RESIDUAL) && (ldr & 3)))
         return MVIT_EUNSUPPORTED;
 #define DISPATCH(TA, TO) \
     return launch_linear_mfma<TA, TO>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
     static const bool use_dma = getenv("MVIT_GEMM_NO_DMA") == nullptr;
     static const bool use_big = getenv("MVIT_GEMM_NO_BIG") == nullptr;
-    if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && K % G_BK == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
+    if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && G_KOK(K) && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
         !(out_dtype == MVIT_BF16 && (epilogue & MVIT_EPI_RESIDUAL))) {
         // persistent form only where the epilogue has no vector loads (measured: with residual / drop-path loads the
         // one-tile-per-workgroup form overlaps them better)
@@ -1172,6 +1184,7 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         if (out_dtype == MVIT_F32)
             return launch_linear_big<float>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
     }
+    if (K % LBK) return MVIT_EUNSUPPORTED;          // the kernels below walk K in 48- / 96-wide slabs
     if (a_dtype == MVIT_BF16 && use_dma && 128 * lda < (1ll << 31)) {
         if (out_dtype == MVIT_BF16)
             return launch_linear_dma<bf16_t>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st);
@@ -1196,7 +1209,7 @@ extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_PERS") == nullptr && getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
-    if (fused && N % G_BN == 0 && K % G_BK == 0 && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
+    if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_pers<bf16_t, 2>(a, lda, w, bias, pre, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
     const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, bias, nullptr, 0, nullptr, 0, pre, MVIT_BF16, N, M, N, K, MVIT_EPI_BIAS, act_dtype, stream);
     if (rc != MVIT_OK) return rc;
@@ -1213,7 +1226,7 @@ extern "C" int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, 
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
-    if (fused && N % G_BN == 0 && K % G_BK == 0 && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
+    if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_big_t<bf16_t, false, false, 1>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
                                                             rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
     const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, nullptr, nullptr, 0, row_scale, rows_per_scale, y, MVIT_BF16, N, M, N, K, 0,
@@ -1231,7 +1244,7 @@ extern "C" int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void
     if (!a || !w || !bias || !dact || !y || M < 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
-    if (N % G_BN || K % G_BK || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
     return launch_linear_pers<bf16_t, 3>(a, lda, w, bias, dact, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
 }
 extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
@@ -1239,7 +1252,7 @@ extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, c
     if (!a || !w || !dact || !y || M < 0 || N <= 0 || K <= 0 || (row_scale && rows_per_scale <= 0)) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
-    if (N % G_BN || K % G_BK || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
     return launch_linear_big_t<bf16_t, false, false, 2>(a, lda, w, nullptr, reinterpret_cast<const float*>(dact), N, row_scale,
                                                         rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
 }

@@ -54,7 +54,8 @@ def test_layernorm(hip_lib, act, C, rows):
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("M,N,K,epi", [(392, 288, 96, "b"), (1000, 96, 384, "br"), (129, 384, 96, "bg"),
-                                        (64, 192, 768, "b"), (257, 96, 96, ""), (512, 576, 192, "brg")])
+                                        (64, 192, 768, "b"), (257, 96, 96, ""), (512, 576, 192, "brg"),
+                                        (300, 384, 160, "b"), (1000, 192, 96, "br"), (128 * 70 + 9, 384, 96, "b")])   # K = 64 j + 32 on the 128x192 kernels
 def test_linear(hip_lib, act, M, N, K, epi):
     a = _act(_rnd(M, K, seed=4), act)
     w = _act(_rnd(N, K, seed=5, scale=0.05), act)
@@ -125,7 +126,7 @@ def test_linear_persistent_many_tiles(hip_lib, epi):
         _close(y, ref.cpu(), 1e-2 if out_bf16 else 2e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 150 + 40, 768, 192), (700, 384, 96), (4096, 1536, 384)])
+@pytest.mark.parametrize("M,N,K", [(128 * 150 + 40, 768, 192), (700, 384, 96), (4096, 1536, 384), (128 * 150 + 40, 384, 96)])
 def test_linear_gelu_dual_output(hip_lib, M, N, K):
     """fc1 of a training step: one GEMM pass writes the pre-activation and GELU(pre) (persistent kernel; K=96 takes the
     plain GEMM + element-wise route).  pre must equal the bias-only GEMM bit for bit; y = GELU of the fp32 accumulator."""
@@ -166,9 +167,11 @@ def test_linear_dgelu(hip_lib, M, N, K):
     _close(y2, (x.grad * (a.float() @ w.float().t())).cpu(), 1.5e-2)
 
 
-def test_linear_gelu_derivative_pair(hip_lib):
-    """fc1 keeps GELU'(pre) instead of pre; the fc2 data gradient multiplies by it: same result as the pre-activation pair."""
-    M, N, K = 128 * 30 + 40, 768, 192
+@pytest.mark.parametrize("N,K,K2", [(768, 192, 192), (384, 96, 96)])
+def test_linear_gelu_derivative_pair(hip_lib, N, K, K2):
+    """fc1 keeps GELU'(pre) instead of pre; the fc2 data gradient multiplies by it: same result as the pre-activation pair.
+    (384, 96, 96) is block 0's MLP: K = 96 runs as one full 64-wide slab plus a half slab."""
+    M = 128 * 30 + 40
     a = _rnd(M, K, seed=51).to(torch.bfloat16).to(DEV)
     w = _rnd(N, K, seed=52, scale=0.08).to(torch.bfloat16).to(DEV)
     bias = _rnd(N, seed=53, scale=0.2).to(DEV)
@@ -182,7 +185,6 @@ def test_linear_gelu_derivative_pair(hip_lib):
     _close(y, g.detach().cpu(), 1e-2)
     _close(dact, x.grad.cpu(), 1e-2)
     # backward side: a2 [M, K2] times w2t [N, K2] (= fc2.weight^T), scaled rows, times the saved derivative
-    K2 = 192
     a2 = _rnd(M, K2, seed=54).to(torch.bfloat16).to(DEV)
     w2t = _rnd(N, K2, seed=55, scale=0.08).to(torch.bfloat16).to(DEV)
     rps = 500
