@@ -817,16 +817,19 @@ static int launch_linear_big(const void* a, int64_t lda, const void* w, const fl
 // ------------------------------------------------------------------------------------------------
 // GELU: 0 = bias only, 1 = bias + GELU, 2 = both (16-bit out): y = GELU(pre) and y2 = pre, the pair a training step keeps;
 // 3 = y = GELU(pre) and y2 = GELU'(pre): the backward then only multiplies (no transcendental in its epilogue)
-template <typename TO, int GELU>   // no residual / row scale (those use linear_big_kernel)
-__global__ __launch_bounds__(256, 2) void linear_pers_kernel(
+// WM = waves along M: 2 = the 128 x 192 tile (4 waves, two workgroups per CU); 4 = a 256 x 192 tile (8 waves, 112 KiB of LDS, one
+// workgroup per CU: 7 instead of 10 LDS-DMA pieces per wave and slab, the weight panel re-read from L2 half as often)
+template <typename TO, int GELU, int WM = 2>   // no residual / row scale (those use linear_big_kernel)
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_pers_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
     TO* __restrict__ y2, int64_t ldr, const float* __restrict__ row_scale, int64_t rows_per_scale,
     TO* __restrict__ y, int64_t ldy, int64_t M, int N, int K, int epilogue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = (sizeof(TO) == 4 ? 24 : 12) * (GELU >= 2 ? 2 : 1);     // vector stores per wave per full tile
+    constexpr int BM = 64 * WM, PANEL_A = BM * G_ROWB, BUF = PANEL_A + G_PANEL_B, NB = 12 / WM;   // NB: weight-panel pieces per wave
 
     const int ntn = N / G_BN;
-    const int nt = (int)((M + G_BM - 1) / G_BM) * ntn;
+    const int nt = (int)((M + BM - 1) / BM) * ntn;
     const int per = gridDim.x >> 3;                     // workgroups per XCD (grid is a multiple of 8)
     const int q = (nt + 7) >> 3;
     const int xcd = blockIdx.x & 7;
@@ -840,15 +843,15 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     const int r = lane & 31, h = lane >> 5;
 
     // DMA piece p (1 KiB = 8 rows x 128 B): lane -> row 8p + lane/8, position lane%8, logical chunk pos ^ swz(row)
-    int a_row[4], a_chunk[4], b_off[6];
+    int a_row[4], a_chunk[4], b_off[NB];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         a_row[i] = 8 * (4 * wave + i) + (lane >> 3);
         a_chunk[i] = 8 * ((lane & 7) ^ ((a_row[i] >> 1) & 7));
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int row = 8 * (6 * wave + i) + (lane >> 3);
+    for (int i = 0; i < NB; ++i) {
+        const int row = 8 * (NB * wave + i) + (lane >> 3);
         b_off[i] = row * K + 8 * ((lane & 7) ^ ((row >> 1) & 7));
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     for (int ks = 0; ks < 4; ++ks) {
         const int fo = ((2 * ks + h) ^ ((r >> 1) & 7)) * 16;
         lds_x[ks] = lds0 + (64 * wm + r) * G_ROWB + fo;                 // token rows  (MFMA B operand)
-        lds_w[ks] = lds0 + G_PANEL_A + (96 * wn + r) * G_ROWB + fo;     // weight rows (MFMA A operand)
+        lds_w[ks] = lds0 + PANEL_A + (96 * wn + r) * G_ROWB + fo;       // weight rows (MFMA A operand)
     }
     const int nk = (K + G_BK - 1) / G_BK;           // K = 64 j + 32: see linear_big_kernel
     const bool ktail = (K & (G_BK - 1)) != 0;
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     const bf16_t* a_src[4];
     const bf16_t* w_src;
     auto setup = [&](int tile) {
-        const int64_t m0 = (int64_t)(tile / ntn) * G_BM;
+        const int64_t m0 = (int64_t)(tile / ntn) * BM;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int64_t m = m0 + a_row[i];
@@ -876,14 +879,14 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
         w_src = w + (int64_t)(tile % ntn) * G_BN * K;
     };
     auto dma = [&](int k0, int buf) {
-        char* base = smem + buf * G_BUF;
+        char* base = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + k0), (lptr_t*)(base + 1024 * (4 * wave + i)), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(w_src + b_off[i] + k0),
-                                             (lptr_t*)(base + G_PANEL_A + 1024 * (6 * wave + i)), 16, 0, 0);
+                                             (lptr_t*)(base + PANEL_A + 1024 * (NB * wave + i)), 16, 0, 0);
     };
 
     setup(t);
@@ -892,9 +895,9 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     bool trail = false;         // the previous tile left exactly NST stores behind the slab-0 DMA
     for (;;) {
         const int tn = t % ntn;
-        const int64_t m0 = (int64_t)(t / ntn) * G_BM;
+        const int64_t m0 = (int64_t)(t / ntn) * BM;
         const int n0 = tn * G_BN;
-        const bool full_m = m0 + G_BM <= M;
+        const bool full_m = m0 + BM <= M;
         const int t_next = t + per;
         const bool has_next = t_next < t_end;
 
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
             if (kt + 1 < nk) dma((ktail && kt + 2 == nk) ? K - G_BK : (kt + 1) * G_BK, (s + 1) & 1);
             else if (has_next) { setup(t_next); dma(0, (s + 1) & 1); }
             const bool half = ktail && kt + 1 == nk;
-            const uint32_t bo = (s & 1) ? G_BUF : 0;
+            const uint32_t bo = (s & 1) ? BUF : 0;
             bf16x8 xf[4][2], wf[4][3];
 #define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
                  xf[KS][0] = lds_read128<0>(xa); xf[KS][1] = lds_read128<32 * G_ROWB>(xa); \
@@ -1029,25 +1032,40 @@ __global__ __launch_bounds__(256, 2) void linear_pers_kernel(
     }
 }
 
-template <typename TO, int GELU>
-static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, void* y2,
-                              int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
-                              int K, int epi, hipStream_t st) {
-    const int64_t nt = ((M + G_BM - 1) / G_BM) * (N / G_BN);
+template <typename TO, int GELU, int WM>
+static int launch_linear_pers_t(const void* a, int64_t lda, const void* w, const float* bias, void* y2,
+                                int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                                int K, int epi, hipStream_t st) {
+    constexpr int BM = 64 * WM, SMEM = 2 * (BM * G_ROWB + G_PANEL_B);
+    const int64_t nt = ((M + BM - 1) / BM) * (N / G_BN);
     if (nt > 0x7fffffff) return MVIT_EINVAL;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO, GELU>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO, GELU, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
     const int64_t q = (nt + 7) / 8;
-    const int per = (int)(q < 64 ? q : 64);             // 2 workgroups per CU x 32 CUs per XCD
-    hipLaunchKernelGGL((linear_pers_kernel<TO, GELU>), dim3((unsigned)(8 * per)), dim3(256), G_SMEM, st, (const bf16_t*)a, lda,
+    constexpr int slots = WM == 2 ? 64 : 32;            // resident workgroups per XCD (2 or 1 per CU x 32 CUs)
+    const int per = (int)(q < slots ? q : slots);
+    hipLaunchKernelGGL((linear_pers_kernel<TO, GELU, WM>), dim3((unsigned)(8 * per)), dim3(128 * WM), SMEM, st, (const bf16_t*)a, lda,
                        (const bf16_t*)w, bias, (TO*)y2, ldr, row_scale, rps, (TO*)y, ldy, M, N, K, epi);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+template <typename TO, int GELU>
+static int launch_linear_pers(const void* a, int64_t lda, const void* w, const float* bias, void* y2,
+                              int64_t ldr, const float* row_scale, int64_t rps, void* y, int64_t ldy, int64_t M, int N,
+                              int K, int epi, hipStream_t st) {
+    // Measured on the model's shapes (profiles/r2_gemm_bm256_ab.txt): the 256-row, 8-wave tile is within +-2 % of the 128-row one
+    // for K = 384, 6-8 % faster for K >= 1536 with a plain epilogue (fc1 data gradient) and 6-13 % slower with the GELU
+    // epilogues and on the 12,544-row stage (one workgroup per CU: nobody's MFMAs run under its epilogue).  MVIT_GEMM_BM256=1/0 forces.
+    static const char* env = getenv("MVIT_GEMM_BM256");
+    const bool bm256 = env ? env[0] == '1' : (GELU == 0 && K >= 1024 && M >= 32768);
+    if (bm256 && 512 * lda < (1ll << 31))
+        return launch_linear_pers_t<TO, GELU, 4>(a, lda, w, bias, y2, ldr, row_scale, rps, y, ldy, M, N, K, epi, st);
+    return launch_linear_pers_t<TO, GELU, 2>(a, lda, w, bias, y2, ldr, row_scale, rps, y, ldy, M, N, K, epi, st);
 }
 
 template <typename TA, typename TO>
