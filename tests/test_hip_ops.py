@@ -55,7 +55,8 @@ def test_layernorm(hip_lib, act, C, rows):
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("M,N,K,epi", [(392, 288, 96, "b"), (1000, 96, 384, "br"), (129, 384, 96, "bg"),
                                         (64, 192, 768, "b"), (257, 96, 96, ""), (512, 576, 192, "brg"),
-                                        (300, 384, 160, "b"), (1000, 192, 96, "br"), (128 * 70 + 9, 384, 96, "b")])   # K = 64 j + 32 on the 128x192 kernels
+                                        (300, 384, 160, "b"), (1000, 192, 96, "br"), (128 * 70 + 9, 384, 96, "b"),   # K = 64 j + 32 on the 128x192 kernels
+                                        (32768 + 40, 192, 1024, "b")])                                               # long K, many rows: the 256-row / 8-wave tile
 def test_linear(hip_lib, act, M, N, K, epi):
     a = _act(_rnd(M, K, seed=4), act)
     w = _act(_rnd(N, K, seed=5, scale=0.05), act)
