@@ -495,9 +495,11 @@ static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd,
     if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !scaled && N % 32 == 0 && K % 32 == 0 && N >= 32 && K >= 32 && M % 64 == 0 &&
         64 * lda < (1ll << 31) && 64 * ldd < (1ll << 31)) {
         const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
-        // M chunks: fewer, longer chunks (each ends with a 128x192 fp32 tile going to its slab / to atomics) as long as the grid
-        // stays inside ONE round of resident workgroups (512 slots): 384 measured best for the 12-24-tile layers, 256 for layers
-        // with few tiles (MVIT_WGRAD_WGS overrides)
+        // M chunks: fewer, longer chunks (each ends with a 96 KiB fp32 tile going to its slab) as long as the grid stays inside ONE
+        // round of resident workgroups (512 slots; 528 workgroups ran 17 % slower than 456 on the fc1 shape).  Alone on the chip the
+        // best count is the largest that fits (profiles/r2_wgrad_wgs_sweep.txt: 456-504 workgroups, -5 %); inside the step, where
+        // these GEMMs share the chip with the data-gradient stream, ~384 (256 for layers with <= 8 tiles) measured 0.1 ms better
+        // than that (3 x 3 runs in one session), so it stays.  MVIT_WGRAD_WGS overrides.
         static const int wg_env = getenv("MVIT_WGRAD_WGS") ? atoi(getenv("MVIT_WGRAD_WGS")) : 0;
         const int wg_target = wg_env > 0 ? wg_env : (bt <= 8 ? 256 : 384);
         int64_t nch = (wg_target + bt - 1) / bt;

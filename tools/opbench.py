@@ -114,9 +114,12 @@ def main():
         dW = torch.zeros(N, K, device=dev)
         db = torch.zeros(N, device=dev)
 
+        nb = L.mvit_linear_wgrad_workspace_bytes(_hip.BF16, K, _hip.BF16, N, 0, M, N, K, _hip.BF16)     # slab form (what training runs)
+        ws = torch.empty(max(nb // 4, 1), device=dev) if not os.environ.get("OPB_WGRAD_ATOMICS") else None
+
         def fn():
-            _hip.check(L.mvit_linear_wgrad(_hip.ptr(x), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
-                                           _hip.BF16, st))
+            _hip.check(L.mvit_linear_wgrad2(_hip.ptr(x), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
+                                            _hip.BF16, _hip.ptr(ws), nb if ws is not None else 0, st))
         ms = timeit(fn, reps)
         print("wgrad M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s" % (M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
     elif op == "pool":
