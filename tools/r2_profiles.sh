@@ -28,3 +28,9 @@ MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd8_hbm_traffi
 rm -rf gpurun_out/traffic
 MARKER=attn_bwd_delta tools/traffic.sh attn_bwd gpurun_out/${pre}_attn_bwd_hbm_traffic.json --mode train > /dev/null 2>&1
 rm -rf gpurun_out/traffic
+# where the copyBuffer launches fall (initialisation vs per-step)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $root/gpurun_out/${pre}_when -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-forward-record > /dev/null 2>&1
+cd $root
+(python3 tools/ktrace_when.py gpurun_out/${pre}_when copyBuffer; python3 tools/ktrace_when.py gpurun_out/${pre}_when compare_scalar; python3 tools/ktrace_when.py gpurun_out/${pre}_when reduce_partials) > gpurun_out/${pre}_launch_phases.txt 2>&1
+rm -rf gpurun_out/${pre}_when
