@@ -387,3 +387,123 @@ def test_cast_transpose(hip_lib, R, C):
     dt2 = torch.zeros_like(dt)
     _hip.check(hip_lib.mvit_cast_transpose_f32_to_bf16(_hip.ptr(xd), None, _hip.ptr(dt2), R, C, _st()))
     assert torch.equal(dt2.cpu(), ref.t().contiguous())
+
+
+# ---- round-2 entry points: the deterministic / fused forms must agree with the forms they replace -------------------------------
+
+@pytest.mark.parametrize("C,rows,rps", [(96, 1000, 250), (384, 392 * 4, 392), (768, 130, 0)])
+def test_layernorm_bwd3_emits_the_cast_of_its_own_result(hip_lib, C, rows, rps):
+    """mvit_layernorm_bwd3's 16-bit side output is bit for bit mvit_cast_rows_f32_to_bf16 of the dx it wrote, and dx / d_gamma /
+    d_beta are unchanged by asking for it."""
+    x = (_rnd(rows, C, seed=61) * 2 + 0.3).to(DEV)
+    g = (1 + 0.1 * _rnd(C, seed=62)).to(DEV)
+    dy = _rnd(rows, C, seed=63).to(torch.bfloat16).to(DEV)
+    base = _rnd(rows, C, seed=64).to(DEV)
+    sc = (torch.rand((rows + rps - 1) // rps, generator=torch.Generator().manual_seed(7)) * 2).to(DEV) if rps else None
+    nws = hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4
+    outs = []
+    for emit in (False, True):
+        dx = torch.empty(rows, C, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx16 = torch.zeros(rows, C, dtype=torch.bfloat16, device=DEV)
+        ws = torch.empty(nws, device=DEV)
+        _hip.check(hip_lib.mvit_layernorm_bwd3(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.BF16, 1, 1.0, _hip.ptr(base), _hip.ptr(dx),
+                                               _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws), rows, C, 1e-6,
+                                               _hip.ptr(dx16) if emit else None, _hip.ptr(sc) if emit else None, rps if emit and rps else 0, _st()))
+        outs.append((dx, dg, db, dx16))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    ref16 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_cast_rows_f32_to_bf16(_hip.ptr(outs[1][0]), _hip.ptr(ref16), rows, C, _hip.ptr(sc), rps, _st()))
+    assert torch.equal(outs[1][3], ref16)
+
+
+def test_reduce_queue_gives_the_bits_of_the_immediate_reductions(hip_lib):
+    """Queued (one launch at the flush) and immediate parameter-gradient reductions of LayerNorm backwards: identical sums; more
+    entries than the queue holds flush themselves."""
+    torch.manual_seed(3)
+    cases = [(384, 3000), (96, 5000), (768, 700), (192, 64)] * 5          # 20 > the queue's 16 slots
+    xs = [(torch.randn(r, C, device=DEV) * 2, 1 + 0.1 * torch.randn(C, device=DEV), torch.randn(r, C, device=DEV)) for C, r in cases]
+
+    def run(queued):
+        res, keep = [], []
+        if queued:
+            _hip.check(hip_lib.mvit_reduce_queue_begin())
+        for (C, r), (x, g, dy) in zip(cases, xs):
+            dx = torch.empty_like(x)
+            dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
+            keep.append(ws)                      # the contract: workspaces stay untouched until the flush
+            _hip.check(hip_lib.mvit_layernorm_bwd2(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.F32, 1, 1.0, None, _hip.ptr(dx), _hip.ptr(dg),
+                                                   _hip.ptr(db), 0, _hip.ptr(ws), r, C, 1e-6, _st()))
+            res.append((dg, db))
+        if queued:
+            _hip.check(hip_lib.mvit_reduce_queue_flush(_st()))
+        torch.cuda.synchronize()
+        return res
+    imm, que = run(False), run(True)
+    for (a0, a1), (b0, b1) in zip(imm, que):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    ref = (xs[0][2] * 1.0).sum(0)               # d_beta = column sums of dy
+    _close(imm[0][1], ref.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(6336, 384, 192), (4096, 1152, 384), (64 * 900, 192, 96), (3000, 96, 96)])
+def test_linear_wgrad2_slab_form_is_reproducible_and_matches(hip_lib, M, N, K):
+    """The slab form (workspace) of the weight gradient: equal to the reference product, bit-identical between two runs, and
+    within rounding of the atomics form it replaces."""
+    a = _rnd(M, K, seed=71).to(torch.bfloat16).to(DEV)
+    dy = _rnd(M, N, seed=72).to(torch.bfloat16).to(DEV)
+    ref = (dy.float().t() @ a.float()).cpu()
+    nb = hip_lib.mvit_linear_wgrad_workspace_bytes(_hip.BF16, K, _hip.BF16, N, 0, M, N, K, _hip.BF16)
+    assert nb > 0
+    outs = []
+    for _ in range(2):
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ws = torch.empty(nb // 4, device=DEV)
+        _hip.check(hip_lib.mvit_linear_wgrad2(_hip.ptr(a), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
+                                              _hip.BF16, _hip.ptr(ws), nb, _st()))
+        outs.append((dW, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    _close(outs[0][0], ref, 2e-3)
+    _close(outs[0][1], dy.float().sum(0).cpu(), 2e-3)
+    dW2, db2 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(a), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW2), _hip.ptr(db2), M, N, K,
+                                         _hip.BF16, _st()))
+    _close(dW2, outs[0][0].cpu(), 1e-4)
+
+
+def test_adamw_step_dev_equals_adamw_step(hip_lib):
+    """The captured-step form (lr and bias corrections read from device memory) gives the bits of the host-scalar form, also on
+    gradients that are not 16-byte aligned (views into a DistributedDataParallel bucket)."""
+    import math
+    torch.manual_seed(5)
+    n = 70001
+    flat = torch.randn(4 * n + 8, device=DEV)
+    dt = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i4"), ("wd", "f4")])
+    res = []
+    for variant in ("host", "dev", "host-unaligned"):
+        p = flat[:n].clone()
+        gsrc = torch.randn(n + 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+        g = gsrc[1:n + 1] if variant == "host-unaligned" else gsrc[1:n + 1].clone()       # the view starts 4 bytes off a 16-byte boundary
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        CH = 65536
+        rec = [(p.data_ptr() + 4 * o, g.data_ptr() + 4 * o, m.data_ptr() + 4 * o, v.data_ptr() + 4 * o, min(CH, n - o), 1e-4) for o in range(0, n, CH)]
+        table = torch.from_numpy(np.array(rec, dtype=dt).view(np.uint8).copy()).to(DEV)
+        partials, out2 = torch.empty(len(rec), device=DEV), torch.empty(2, device=DEV)
+        for step in (1, 2, 3):
+            _hip.check(hip_lib.mvit_grad_norm(_hip.ptr(table), len(rec), 1.0, _hip.ptr(partials), _hip.ptr(out2), _st()))
+            if variant == "dev":
+                f32 = lambda x: ctypes.c_float(x).value
+                libm = ctypes.CDLL("libm.so.6")
+                libm.powf.restype = ctypes.c_float; libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+                libm.sqrtf.restype = ctypes.c_float; libm.sqrtf.argtypes = [ctypes.c_float]
+                hyper = torch.tensor([1e-3, f32(1.0 - libm.powf(0.9, float(step))), libm.sqrtf(f32(1.0 - libm.powf(0.999, float(step))))],
+                                     dtype=torch.float32, device=DEV)
+                _hip.check(hip_lib.mvit_adamw_step_dev(_hip.ptr(table), len(rec), _hip.ptr(out2), _hip.ptr(hyper), 0.9, 0.999, 1e-8, _st()))
+            else:
+                _hip.check(hip_lib.mvit_adamw_step(_hip.ptr(table), len(rec), _hip.ptr(out2), 1e-3, 0.9, 0.999, 1e-8, step, _st()))
+        res.append((p.clone(), m.clone(), v.clone(), out2.clone()))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
