@@ -86,6 +86,52 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const T* __restrict
     }
 }
 
+// 16-bit form: the [B][Lq][heads*96] tensors are walked as one flat stream of 16-byte chunks (thread = chunk, fully coalesced:
+// 192 threads x 16 B = 3 KiB contiguous per load; the 4-lanes-per-row kernel above touched sixteen 64-byte pieces of sixteen rows
+// per wave-instruction and ran at 2.7 TB/s); the twelve chunk sums of a (b, q, head) meet in LDS.  192 = 16 x 12 threads and
+// every row is a multiple of twelve chunks, so a group never straddles a workgroup or a row.
+__global__ __launch_bounds__(192) void attn_bwd_delta_flat_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                                  const bf16_t* __restrict__ Q, float* __restrict__ delta,
+                                                                  int heads, int Lq, int64_t nchunks, int add_q) {
+    __shared__ float part[192];
+    const int cpr = 12 * heads;                                    // chunks per (b, q) row
+    for (int64_t c0 = (int64_t)blockIdx.x * 192; c0 < nchunks; c0 += (int64_t)gridDim.x * 192) {
+        const int64_t c = c0 + threadIdx.x;
+        float s = 0.f;
+        int64_t it = 0;
+        if (c < nchunks) {
+            const int64_t row = c / cpr;                           // b * Lq + q
+            const int cin = (int)(c - row * cpr), g = cin / 12, k = cin - 12 * g;
+            const int64_t b = row / Lq, q = row - b * Lq;
+            it = (b * heads + g) * Lq + q;
+            float4 d0, d1, o0, o1;
+            load8(dO + c * 8, d0, d1);
+            load8(O + c * 8, o0, o1);
+            if (add_q) {
+                float4 q0, q1;
+                load8(Q + it * 96 + 8 * k, q0, q1);
+                o0.x -= q0.x; o0.y -= q0.y; o0.z -= q0.z; o0.w -= q0.w;
+                o1.x -= q1.x; o1.y -= q1.y; o1.z -= q1.z; o1.w -= q1.w;
+            }
+            s = (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y) + (d1.z * o1.z + d1.w * o1.w);
+        }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int64_t cg = c0 + 12 * threadIdx.x;              // first chunk of this group
+            if (cg < nchunks) {
+                const float* p = part + 12 * threadIdx.x;
+                const float t = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) + ((p[8] + p[9]) + (p[10] + p[11]));
+                const int64_t row = cg / cpr;
+                const int g = (int)(cg - row * cpr) / 12;
+                const int64_t b = row / Lq, q = row - b * Lq;
+                delta[(b * heads + g) * Lq + q] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass A (bf16 MFMA): dQ.   grid (ceil(Lq/128), B*heads), 4 waves x 32 queries.
 // ------------------------------------------------------------------------------------------------
@@ -758,8 +804,17 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
     if (dblocks > 16384) dblocks = 16384;
     const float sl2 = scale * 1.44269504088896340736f;
     if (act_dtype == MVIT_BF16) {
-        hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t>), dim3((unsigned)dblocks), dim3(256), 0, st, (const bf16_t*)dout,
-                           (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
+        static const bool flat_delta = getenv("MVIT_ATT_DELTA_ROWS") == nullptr;
+        if (flat_delta) {
+            const int64_t nchunks = rows * 12;
+            int64_t fb = (nchunks + 191) / 192;
+            if (fb > 8192) fb = 8192;
+            hipLaunchKernelGGL(attn_bwd_delta_flat_kernel, dim3((unsigned)fb), dim3(192), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
+                               (const bf16_t*)q, workspace, heads, Lq, nchunks, add_q);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t>), dim3((unsigned)dblocks), dim3(256), 0, st, (const bf16_t*)dout,
+                               (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
+        }
         MVIT_LAUNCH_CHECK();
         // the dQ pass (on st) and the dK/dV pass only share their inputs and delta: fork here, right behind the delta kernel, and
         // issue the dK/dV pass on the library's side stream so the two passes fill each other's partial last waves of workgroups
