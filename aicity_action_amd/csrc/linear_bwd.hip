@@ -197,12 +197,19 @@ __device__ __forceinline__ bf16x8 wb_join(const bf16x4 (&f)[2]) {
     return v;
 }
 
+// KHALF (K <= 96: the 96-wide layers of blocks 0 and 1, 0.9 ms of weight gradients per step): a 192-wide k tile would be half
+// padding -- the wq = 1 waves multiplied clamped columns whose results were dropped.  Here the a image is 64 rows x 192 B (three
+// DMA pieces per wave instead of six, no swizzle needed: consecutive 192-byte rows already fall in different bank quarters), both
+// wave columns work on the same 96 k columns and split the 64 slab rows between them (wq = 0: rows 0-31, wq = 1: rows 32-63:
+// two k-steps each), and the two partial tiles meet in LDS after the last slab (wq = 1 parks, wq = 0 adds and stores).
+template <bool KHALF>
 __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restrict__ a, int64_t lda,
                                                            const bf16_t* __restrict__ dy, int64_t ldd,
                                                            float* __restrict__ dW, float* __restrict__ db, int64_t M, int N,
                                                            int K, int mchunk, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntq = (K + WB_BQ - 1) / WB_BQ;      // ragged last tiles (N, K multiples of 32): sources clamped, results masked
+    constexpr int QROWB = KHALF ? 192 : WB_QROWB, PANEL_Q = 64 * QROWB, BUF = WB_PANEL_P + PANEL_Q, NQ = KHALF ? 3 : 6, CPR = QROWB / 16;
+    const int ntq = KHALF ? 1 : (K + WB_BQ - 1) / WB_BQ;      // ragged last tiles (N, K multiples of 32): sources clamped, results masked
     const int n0 = (blockIdx.x / ntq) * WB_BP, k0 = (blockIdx.x % ntq) * WB_BQ;
     const int64_t mbeg = (int64_t)blockIdx.y * mchunk;
     const int64_t mend = mbeg + mchunk < M ? mbeg + mchunk : M;     // multiple of 64 (checked by the launcher)
@@ -210,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wp = wave >> 1, wq = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const bool do_bias = db != nullptr && k0 == 0 && wq == 0;       // wave-uniform
+    const bool do_bias = db != nullptr && k0 == 0 && (KHALF || wq == 0);       // wave-uniform
 
     // DMA sources (per lane, relative to the slab's first row)
-    int64_t p_src[4], q_src[6];
+    int64_t p_src[4], q_src[NQ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {       // dy image: piece = 4 rows x 256 B
         const int row = 4 * (4 * wave + i) + (lane >> 4), c = lane & 15;
@@ -223,24 +230,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
         p_src[i] = (int64_t)row * ldd + col;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {       // a image: 24 chunks per row, pieces run across rows
-        const int x = 64 * (6 * wave + i) + lane;
-        const int row = x / 24, c = x - row * 24;
-        const int seg = (c >> 2) ^ ((row >> 1) & 1);
+    for (int i = 0; i < NQ; ++i) {      // a image: 24 (12) chunks per row, pieces run across rows
+        const int x = 64 * (NQ * wave + i) + lane;
+        const int row = x / CPR, c = x - row * CPR;
+        const int seg = KHALF ? (c >> 2) : ((c >> 2) ^ ((row >> 1) & 1));
         int col = k0 + 8 * (4 * seg + (c & 3));
         col = col + 8 <= K ? col : K - 8;
         q_src[i] = (int64_t)row * lda + col;
     }
     auto dma = [&](int64_t m0, int buf) {
-        char* base = smem + buf * WB_BUF;
+        char* base = smem + buf * BUF;
         const bf16_t* ps = dy + m0 * ldd;
         const bf16_t* qs = a + m0 * lda;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((wb_gptr_t*)(ps + p_src[i]), (wb_lptr_t*)(base + 1024 * (4 * wave + i)), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_global_load_lds((wb_gptr_t*)(qs + q_src[i]), (wb_lptr_t*)(base + WB_PANEL_P + 1024 * (6 * wave + i)), 16, 0, 0);
+        for (int i = 0; i < NQ; ++i)
+            __builtin_amdgcn_global_load_lds((wb_gptr_t*)(qs + q_src[i]), (wb_lptr_t*)(base + WB_PANEL_P + 1024 * (NQ * wave + i)), 16, 0, 0);
     };
 
     // transposing fragment reads: lane supplies row 8h + (i16>>2) (+4 for the second half) and 8 bytes at
@@ -250,9 +257,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
     const int rr = 8 * h + (i16 >> 2), inseg = 32 * (gi & 1) + 8 * (i16 & 3);
     uint32_t pa[2], qa[3];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) pa[pb] = lds0 + rr * WB_PROWB + 64 * ((2 * wp + pb) ^ (i16 >> 2)) + inseg;
+    for (int pb = 0; pb < 2; ++pb) pa[pb] = lds0 + (rr + (KHALF ? 32 * wq : 0)) * WB_PROWB + 64 * ((2 * wp + pb) ^ (i16 >> 2)) + inseg;
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) qa[qb] = lds0 + WB_PANEL_P + rr * WB_QROWB + 64 * ((3 * wq + qb) ^ ((i16 >> 3) & 1)) + inseg;
+    for (int qb = 0; qb < 3; ++qb)
+        qa[qb] = KHALF ? lds0 + WB_PANEL_P + (rr + 32 * wq) * QROWB + 64 * qb + inseg
+                       : lds0 + WB_PANEL_P + rr * QROWB + 64 * ((3 * wq + qb) ^ ((i16 >> 3) & 1)) + inseg;
 
     f32x16 acc[2][3], bacc[2];
 #pragma unroll
@@ -274,14 +283,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (sl + 1 < nslab) dma(mbeg + 64 * (int64_t)(sl + 1), (sl + 1) & 1);
-        const uint32_t bo = (sl & 1) ? WB_BUF : 0;
-        bf16x4 f[4][5][2];      // [k-step][P0 P1 Q0 Q1 Q2][lo hi]
+        const uint32_t bo = (sl & 1) ? BUF : 0;
+        bf16x4 f[KHALF ? 2 : 4][5][2];      // [k-step][P0 P1 Q0 Q1 Q2][lo hi]
 #define RD(KS) { \
             f[KS][0][0] = wb_tr<KS * 16 * WB_PROWB>(pa[0] + bo); f[KS][0][1] = wb_tr<KS * 16 * WB_PROWB + 4 * WB_PROWB>(pa[0] + bo); \
             f[KS][1][0] = wb_tr<KS * 16 * WB_PROWB>(pa[1] + bo); f[KS][1][1] = wb_tr<KS * 16 * WB_PROWB + 4 * WB_PROWB>(pa[1] + bo); \
-            f[KS][2][0] = wb_tr<KS * 16 * WB_QROWB>(qa[0] + bo); f[KS][2][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[0] + bo); \
-            f[KS][3][0] = wb_tr<KS * 16 * WB_QROWB>(qa[1] + bo); f[KS][3][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[1] + bo); \
-            f[KS][4][0] = wb_tr<KS * 16 * WB_QROWB>(qa[2] + bo); f[KS][4][1] = wb_tr<KS * 16 * WB_QROWB + 4 * WB_QROWB>(qa[2] + bo); }
+            f[KS][2][0] = wb_tr<KS * 16 * QROWB>(qa[0] + bo); f[KS][2][1] = wb_tr<KS * 16 * QROWB + 4 * QROWB>(qa[0] + bo); \
+            f[KS][3][0] = wb_tr<KS * 16 * QROWB>(qa[1] + bo); f[KS][3][1] = wb_tr<KS * 16 * QROWB + 4 * QROWB>(qa[1] + bo); \
+            f[KS][4][0] = wb_tr<KS * 16 * QROWB>(qa[2] + bo); f[KS][4][1] = wb_tr<KS * 16 * QROWB + 4 * QROWB>(qa[2] + bo); }
 #define MM(KS) { \
             const bf16x8 p0 = wb_join(f[KS][0]), p1 = wb_join(f[KS][1]); \
             const bf16x8 q0 = wb_join(f[KS][2]), q1 = wb_join(f[KS][3]), q2 = wb_join(f[KS][4]); \
@@ -291,20 +300,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
             if (do_bias) { bacc[0] = mfma16(p0, ones, bacc[0]); bacc[1] = mfma16(p1, ones, bacc[1]); } }
         RD(0) RD(1)
         wb_wait5(f[0], 10);
-        RD(2)
-        MM(0)
-        __builtin_amdgcn_sched_barrier(0);
-        wb_wait5(f[1], 10);
-        RD(3)
-        MM(1)
-        __builtin_amdgcn_sched_barrier(0);
-        wb_wait5(f[2], 10);
-        MM(2)
-        __builtin_amdgcn_sched_barrier(0);
-        wb_wait5(f[3], 0);
-        MM(3)
+        if constexpr (KHALF) {
+            MM(0)
+            __builtin_amdgcn_sched_barrier(0);
+            wb_wait5(f[1], 0);
+            MM(1)
+        } else {
+            RD(2)
+            MM(0)
+            __builtin_amdgcn_sched_barrier(0);
+            wb_wait5(f[1], 10);
+            RD(3)
+            MM(1)
+            __builtin_amdgcn_sched_barrier(0);
+            wb_wait5(f[2], 10);
+            MM(2)
+            __builtin_amdgcn_sched_barrier(0);
+            wb_wait5(f[3], 0);
+            MM(3)
+        }
 #undef RD
 #undef MM
+    }
+    if constexpr (KHALF) {      // the two row halves meet: wq = 1 parks its tile (lane-contiguous), wq = 0 adds it
+        float* park = reinterpret_cast<float*>(smem);
+        __syncthreads();        // every wave is done reading the last slab
+        if (wq == 1) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) park[((((wp * 2 + pb) * 3 + qb) * 16 + i) << 6) + lane] = acc[pb][qb][i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) park[12288 + (((wp * 2 + pb) * 16 + i) << 6) + lane] = bacc[pb][i];
+            }
+        }
+        __syncthreads();
+        if (wq == 1) return;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[pb][qb][i] += park[((((wp * 2 + pb) * 3 + qb) * 16 + i) << 6) + lane];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[pb][i] += park[12288 + (((wp * 2 + pb) * 16 + i) << 6) + lane];
+        }
     }
     // acc[pb][qb][i]: row n = n0 + 64wp + 32pb + (i&3) + 8(i>>2) + 4h, col k = k0 + 96wq + 32qb + r -> 128 contiguous bytes
     if (part) {      // this M chunk's tile to its own slab, plain stores (summed in chunk order by wgrad_reduce_kernel)
@@ -316,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const int kk = k0 + 96 * wq + 32 * qb + r;
+                    const int kk = k0 + (KHALF ? 0 : 96 * wq) + 32 * qb + r;
                     if (n < N && kk < K) oW[(int64_t)n * K + kk] = acc[pb][qb][i];
                 }
         if (do_bias && r == 0) {
@@ -337,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int kk = k0 + 96 * wq + 32 * qb + r;
+                const int kk = k0 + (KHALF ? 0 : 96 * wq) + 32 * qb + r;
 #ifdef WB_ABL
                 if (n < N && kk < K && acc[pb][qb][i] == 12345.678f) dW[(int64_t)n * K + kk] = 0.f;
 #else
@@ -542,14 +584,20 @@ extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const
     } else if (p.path == 1) {
         static bool attr_done = false;
         if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess)
                 return MVIT_ELAUNCH;
             attr_done = true;
         }
         const int64_t bt = (int64_t)((N + WB_BP - 1) / WB_BP) * ((K + WB_BQ - 1) / WB_BQ);
         dim3 bgrid((unsigned)bt, (unsigned)p.nch);
-        hipLaunchKernelGGL(wgrad_big_kernel, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K,
-                           mchunk, part);
+        static const bool khalf_ok = getenv("MVIT_WGRAD_NO_KHALF") == nullptr;
+        if (K <= 96 && khalf_ok)
+            hipLaunchKernelGGL(wgrad_big_kernel<true>, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K,
+                               mchunk, part);
+        else
+            hipLaunchKernelGGL(wgrad_big_kernel<false>, bgrid, dim3(256), WB_SMEM, st, (const bf16_t*)a, lda, (const bf16_t*)dy, ldd, dW, db, M, N, K,
+                               mchunk, part);
     } else {
         dim3 grid((N / 96) * (K / 96), (unsigned)p.nch);
 #define WG(TA, TD) \
