@@ -818,7 +818,12 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         MVIT_LAUNCH_CHECK();
         // the dQ pass (on st) and the dK/dV pass only share their inputs and delta: fork here, right behind the delta kernel, and
         // issue the dK/dV pass on the library's side stream so the two passes fill each other's partial last waves of workgroups
-        SideStream* ss = side_stream_for_current_device();
+        // Measured (profiles/r2_attn_bwd_side_ab.txt): side by side the two passes are 2-4 % faster than one after the other when
+        // the key loop is long (Lk = 6272, the three transition blocks) and 7-11 % SLOWER for Lk = 1568 (each pass alone already fills
+        // the chip; interleaved workgroups of two different kernels share the CUs badly).  MVIT_ATT_BWD_SIDE=0/1 forces.
+        static const char* side_env = getenv("MVIT_ATT_BWD_SIDE");
+        const bool want_side = side_env ? side_env[0] == '1' : Lk > 2048;
+        SideStream* ss = want_side ? side_stream_for_current_device() : nullptr;
         hipStream_t skv = (ss && side_fork(ss, st)) ? ss->side : st;
         dim3 gq((Lq + 127) / 128, B * heads);
         static bool dq_attr_done = false;
