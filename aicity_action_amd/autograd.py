@@ -22,6 +22,10 @@ def _st():
 
 _REDUCE_QUEUE = os.environ.get("MVIT_REDUCE_QUEUE", "1") != "0"     # A/B switch: 0 = every reduction is its own launch
 _LN_EMIT16 = os.environ.get("MVIT_LN_EMIT16", "1") != "0"           # A/B switch: 0 = separate cast passes over the stream gradient
+# k / v pooling convs of the training forward beside the q one on the library's side stream: measured -0.15 ms per step when OFF
+# (profiles/r2_side_stream_ab.txt: since the kernels lost their long tails, interleaving two of them on the CUs costs more than
+# the filled tail returns); MVIT_POOL_FWD_SIDE=1 turns it back on
+_POOL_FWD_SIDE = os.environ.get("MVIT_POOL_FWD_SIDE", "0") == "1"
 
 
 def _ws(nbytes, dev):
@@ -274,7 +278,7 @@ class _BlockFn(torch.autograd.Function):
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:
             _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, _st()), "head_split")
-        forked = L.mvit_side_fork(_st()) == 0          # k / v pooling convs beside the q one (independent readers of qkv)
+        forked = _POOL_FWD_SIDE and L.mvit_side_fork(_st()) == 0      # k / v pooling convs beside the q one (independent readers of qkv)
         side = L.mvit_side_stream() if forked else _st()
         pool_saved = {}     # which -> (xhat, rstd): what the LayerNorm backward needs, so the backward runs no second convolution
         save_ln = os.environ.get("MVIT_POOL_RECOMPUTE", "0") != "1"

@@ -530,6 +530,9 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes2
     const bool tiled = stride_hw == 1 || stride_hw == 2;
     static const bool dgrad_tiled = getenv("MVIT_POOL_DGRAD_GATHER") == nullptr;
+    // the conv weight gradient beside the data gradient on the side stream: -0.55 ms per train step when OFF (profiles/
+    // r2_side_stream_ab.txt; it was a gain in round 1, when the weight gradient ended in atomics and a 96-launch reduce tail)
+    static const bool pool_bwd_side = getenv("MVIT_POOL_BWD_SIDE") != nullptr && getenv("MVIT_POOL_BWD_SIDE")[0] == '1';
     // d_conv is complete after the first kernel; the conv weight gradient (+ its partial-row reduction) only reads it, so it is
     // issued on the library's side stream and runs beside the d_gamma / d_beta reductions and the data gradient
 #define RUN(TA)                                                                                                            \
@@ -542,14 +545,14 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         hipLaunchKernelGGL((pool_ln_bwd_saved_kernel<TA>), dim3((unsigned)bs), dim3(256), 0, st, (const TA*)xhat, rstd, gamma, \
                            (const TA*)dout, (TA*)dconv, workspace, tot_out);                                                \
         MVIT_LAUNCH_CHECK();                                                                                               \
-        ss = side_stream_for_current_device();                                                                             \
+        ss = pool_bwd_side ? side_stream_for_current_device() : nullptr;                                                                             \
         if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, (int)bs, 192, dgamma, dbeta, 96, accumulate_param, st, 1); if (rr_ != MVIT_OK) return rr_; } \
     } else if (tiled) {                                                                                                    \
         const int nrows = mvit_internal_pool_ln_bwd_tiled(qkv, ld, chan_off, w, gamma, dout, dconv, workspace, B, heads, T, \
                                                           H, W, stride_hw, eps, act_dtype, st);                            \
         if (nrows < 0) return nrows;                                                                                       \
-        ss = side_stream_for_current_device();                                                                             \
+        ss = pool_bwd_side ? side_stream_for_current_device() : nullptr;                                                                             \
         if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, nrows, 96, dgamma, dgamma, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
         /* d_beta = column sums of dout (workspace rows are free again after the reduce above, same stream) */             \
@@ -559,7 +562,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         hipLaunchKernelGGL((pool_ln_bwd_kernel<TA>), dim3((unsigned)b1), dim3(256), 0, st, (const TA*)qkv, ld, chan_off, w, \
                            gamma, (const TA*)dout, (TA*)dconv, workspace, B, heads, T, H, W, Ho, Wo, stride_hw, eps);      \
         MVIT_LAUNCH_CHECK();                                                                                               \
-        ss = side_stream_for_current_device();                                                                             \
+        ss = pool_bwd_side ? side_stream_for_current_device() : nullptr;                                                                             \
         if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
     }                                                                                                                      \
