@@ -138,3 +138,19 @@ def check(rc, what=""):
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_STREAMS = {}
+
+
+def shared_streams(dev, n, tag="sub"):
+    """Process-wide torch side streams of a device (n of them under `tag`).  Every model used to create its own pair of
+    sub-batch streams; HIP multiplexes streams onto a handful of hardware queues, so the second model's two streams could land on
+    ONE queue and its sub-batches ran one after the other (17.5 instead of 14.5 ms per forward, tools/fwd_second_model_probe.py).
+    One set per process and device keeps the stream -> queue assignment of the first, working, set."""
+    import torch
+    key = (torch.device(dev).index, tag)
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:n]

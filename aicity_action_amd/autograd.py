@@ -120,10 +120,7 @@ class _Ctx(object):
         if os.environ.get("MVIT_WGRAD_STREAM", "1") == "0" or not (bool(getattr(hip, "WGRAD_STREAM", True)) if hip is not None else True):
             return None
         dev = next(self.m.parameters()).device
-        key = dev.index
-        if getattr(self.m, "_wgrad_stream_key", None) != key:
-            self.m._wgrad_stream = torch.cuda.Stream(device=dev)
-            self.m._wgrad_stream_key = key
+        self.m._wgrad_stream = _hip.shared_streams(dev, 1, "wgrad")[0]
         return self.m._wgrad_stream
 
     def join_side(self):
@@ -542,10 +539,7 @@ def forward_train(model, clip):
     for m in model.modules():                      # weight copies are (re)built once, on the caller's stream
         if isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dim() == 2 and m is not model.head.projection:
             model._w_pair(m.weight, hx.act)
-    key = (dev.index, ns)
-    if getattr(model, "_side_streams_key", None) != key:
-        model._side_streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-        model._side_streams_key = key
+    model._side_streams = _hip.shared_streams(dev, ns)
     cur = torch.cuda.current_stream(dev)
     bounds = [(B * i) // ns for i in range(ns + 1)]
     outs = []

@@ -302,10 +302,7 @@ class MViT(nn.Module):
 
     def _forward_streams(self, clip, return_logits, ns):
         dev = clip.device
-        key = (dev.index, ns)
-        if getattr(self, "_side_streams_key", None) != key:
-            self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
-            self._side_streams_key = key
+        self._side_streams = _hip.shared_streams(dev, ns)       # one set per process and device (see _hip.shared_streams)
         act = _hip.F32 if self.precision == "fp32" else _hip.BF16
         for m in self.modules():                   # 16-bit weight copies are built once, on the caller's stream
             if isinstance(m, nn.Linear) and m.weight.is_cuda:
