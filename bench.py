@@ -324,7 +324,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (BASELINE.md section 4 as far as ~60 s allow) --------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and args.mode != "window":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode != "window":      # N = 1 only (the other ranks would idle behind it)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import mvit_oracle as O
         from aicity_action_amd.utils.synth import synth_state_dict
