@@ -190,6 +190,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     assert torch.isfinite(out).all()
+    if args.mode == "train":
+        # the optimizer skips a step whose global gradient norm is not finite, so a broken backward would leave the loss finite --
+        # and NaN operands switch so little that such a step even times FASTER (data-dependent clock): check the norm itself
+        gn = opt.last_grad_norm
+        assert gn is not None and bool(torch.isfinite(gn).all()), "non-finite gradient norm in the timed steps"
     clips_per_s = world * args.batch * args.steps / dt
     if args.mode == "window":
         clips_per_s = n_windows * args.steps / dt
