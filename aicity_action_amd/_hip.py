@@ -69,6 +69,8 @@ _SIGS = {
     "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd_train": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_bwd_saved": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "mvit_pool_conv_ln_fwd_train_kv": (c_i, [c_p, c_l, c_i] + [c_p] * 9 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "mvit_pool_conv_ln_bwd_saved_kv": (c_i, [c_p, c_l, c_i] + [c_p] * 15 + [c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_fwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_bwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -26,6 +26,9 @@ _LN_EMIT16 = os.environ.get("MVIT_LN_EMIT16", "1") != "0"           # A/B switch
 # (profiles/r2_side_stream_ab.txt: since the kernels lost their long tails, interleaving two of them on the CUs costs more than
 # the filled tail returns); MVIT_POOL_FWD_SIDE=1 turns it back on
 _POOL_FWD_SIDE = os.environ.get("MVIT_POOL_FWD_SIDE", "0") == "1"
+# the k and v pooling convs of a block (and their backward) as ONE set of launches where the library has that form (stride 2:
+# mvit_pool_conv_ln_*_kv); 0 = two single-tensor calls
+_POOL_KV_BATCH = os.environ.get("MVIT_POOL_KV_BATCH", "1") != "0"
 
 
 def _ws(nbytes, dev):
@@ -268,9 +271,10 @@ class _BlockFn(torch.autograd.Function):
         u = hx.ln_fwd(x2, blk.norm1)
         qkv = hx.linear(u, hx.w(at.qkv.weight), at.qkv.bias, adt)
         q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
-        k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        pools = [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
+        kv = torch.empty(2, B, h, Lk, 96, dtype=adt, device=dev)      # k and v back to back (the pair form of the pooling kernels)
+        k, v = kv[0], kv[1]
+        kv_batch = _POOL_KV_BATCH and g.stride_kv[1] == 2 and os.environ.get("MVIT_POOL_RECOMPUTE", "0") != "1"
+        pools = [] if kv_batch else [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
         if g.kernel_q:
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:
@@ -286,6 +290,14 @@ class _BlockFn(torch.autograd.Function):
             _hip.check(L.mvit_pool_conv_ln_fwd_train(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight), _hip.ptr(norm.weight),
                                                      _hip.ptr(norm.bias), _hip.ptr(buf), _hip.ptr(xh), _hip.ptr(rs), B, h, T, H, W, stride,
                                                      norm.eps, act, _st() if which == 0 else side), "pool")
+        if kv_batch:
+            xh_kv = torch.empty_like(kv)
+            rs_kv = torch.empty(2, B * h * Lk, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * Cout, Cout, _hip.ptr(at.pool_k.weight), _hip.ptr(at.norm_k.weight),
+                                                        _hip.ptr(at.norm_k.bias), _hip.ptr(at.pool_v.weight), _hip.ptr(at.norm_v.weight),
+                                                        _hip.ptr(at.norm_v.bias), _hip.ptr(kv), _hip.ptr(xh_kv), _hip.ptr(rs_kv), B, h, T, H, W,
+                                                        g.stride_kv[1], at.norm_k.eps, act, side), "pool_kv")
+            pool_saved["kv"] = (xh_kv, rs_kv)
         if forked:
             _hip.check(L.mvit_side_join(_st()), "side_join")
         o = torch.empty(Mq, Cout, dtype=adt, device=dev)
@@ -393,8 +405,8 @@ class _BlockFn(torch.autograd.Function):
         d_o = hx.linear(g16, hx.wt(at.proj.weight), None, adt, row_scale=gs, rps=grps)
         del g16
         dq = torch.empty_like(q)
-        dk = torch.empty_like(k)
-        dv = torch.empty_like(v)
+        dkv = torch.empty(2, B, h, Lk, 96, dtype=k.dtype, device=dev)
+        dk, dv = dkv[0], dkv[1]
         ws = _ws(L.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk), dev)
         _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(d_o), _hip.ptr(dq),
                                         _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
@@ -405,7 +417,8 @@ class _BlockFn(torch.autograd.Function):
                         L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1]))
         pws = None if defer else _ws(pws_bytes, dev)      # queued reductions: one workspace per pooling conv, kept until the flush
         pool_grads = []
-        bpools = [(1, dk, at.pool_k, at.norm_k, g.stride_kv[1]), (2, dv, at.pool_v, at.norm_v, g.stride_kv[1])]
+        kv_batch = "kv" in pool_saved
+        bpools = [] if kv_batch else [(1, dk, at.pool_k, at.norm_k, g.stride_kv[1]), (2, dv, at.pool_v, at.norm_v, g.stride_kv[1])]
         if g.kernel_q:
             bpools.insert(0, (0, dq, at.pool_q, at.norm_q, g.stride_q[1]))
         else:
@@ -424,6 +437,20 @@ class _BlockFn(torch.autograd.Function):
                                                      _hip.ptr(dw), _hip.ptr(dgm), _hip.ptr(dbt), 1, _hip.ptr(pws), B, h, T, H, W, stride,
                                                      norm.eps, act, _st()), "pool_bwd")
             pool_grads += [dw, dgm, dbt]
+        if kv_batch:      # k and v chains as one set of launches
+            xh_kv, rs_kv = pool_saved["kv"]
+            dconv_kv = torch.empty_like(dkv)
+            pws2 = _ws(2 * L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1]), dev)
+            if defer:
+                hx._red_keep.append(pws2)
+            gk = [hx.zeros(96, 1, 3, 3, 3), hx.zeros(96), hx.zeros(96)]
+            gv = [hx.zeros(96, 1, 3, 3, 3), hx.zeros(96), hx.zeros(96)]
+            _hip.check(L.mvit_pool_conv_ln_bwd_saved_kv(_hip.ptr(qkv), 3 * Cout, Cout, _hip.ptr(at.pool_k.weight), _hip.ptr(at.norm_k.weight),
+                                                        _hip.ptr(at.pool_v.weight), _hip.ptr(at.norm_v.weight), _hip.ptr(xh_kv), _hip.ptr(rs_kv),
+                                                        _hip.ptr(dkv), _hip.ptr(dconv_kv), _hip.ptr(d_qkv), _hip.ptr(gk[0]), _hip.ptr(gk[1]),
+                                                        _hip.ptr(gk[2]), _hip.ptr(gv[0]), _hip.ptr(gv[1]), _hip.ptr(gv[2]), 1, _hip.ptr(pws2),
+                                                        B, h, T, H, W, g.stride_kv[1], act, _st()), "pool_bwd_kv")
+            pool_grads += gk + gv
         dWqkv, dbqkv = hx.wgrad(u, d_qkv, 3 * Cout, Cin)
         d_u = hx.linear(d_qkv, hx.wt(at.qkv.weight), None, adt)
         del d_qkv

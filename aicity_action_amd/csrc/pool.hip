@@ -207,7 +207,12 @@ template <typename TA, int S, bool BWD, bool PLAIN = false>
 __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     const TA* __restrict__ qkv, int64_t ld, int chan_off, const float* __restrict__ w, const float* __restrict__ gamma,
     const float* __restrict__ beta, TA* __restrict__ out, const TA* __restrict__ dout, float* __restrict__ part, int heads,
-    int T, int H, int W, int Ho, int Wo, float eps, int64_t out_ld = 0, int out_chan_off = 0, int out_heads = 1) {
+    int T, int H, int W, int Ho, int Wo, float eps, int64_t out_ld = 0, int out_chan_off = 0, int out_heads = 1,
+    int set_bh = 0, const float* __restrict__ w2 = nullptr, const float* __restrict__ gamma2 = nullptr,
+    const float* __restrict__ beta2 = nullptr) {
+    // set_bh > 0: TWO tensors in one launch (the k and the v pooling conv of a block: adjacent head groups of the fused qkv buffer,
+    // own conv weights / LayerNorm parameters, outputs back to back): blockIdx.y = set * set_bh + (b * heads + g).  One such launch
+    // of the steady 384-wide blocks is 512 workgroups instead of two latency-bound launches of 256 (38 us instead of 2 x 30).
     using P = PoolTile<TA, S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float dgam = 0.f;   // BWD: threads < 96 own one channel of the d_gamma partial (d_beta = column sum of dout, done by the caller)
@@ -218,9 +223,11 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
     const int tiles_x = (Wo + P::XO - 1) / P::XO;
     const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
     const int bh = blockIdx.y;
-    const int b = bh / heads, g = bh - b * heads;
+    int bhs = bh, hoff = 0;
+    if (set_bh > 0 && bh >= set_bh) { bhs = bh - set_bh; hoff = heads; w = w2; gamma = gamma2; beta = beta2; }
+    const int b = bhs / heads, g = bhs - b * heads;
     const int64_t Nin = (int64_t)T * H * W;
-    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + g * 96;
+    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + (hoff + g) * 96;
     const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
 
     float* wl = reinterpret_cast<float*>(smem + P::NBUF * P::IN_BYTES + P::NTOK * 96 * 4);
@@ -463,9 +470,11 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
 template <typename TA, int S>
 static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
                              const float* beta, void* out, void* xhat, float* rstd, int B, int heads, int T, int H, int W, int Ho, int Wo,
-                             float eps, hipStream_t st) {
+                             float eps, hipStream_t st, const float* w2 = nullptr, const float* gamma2 = nullptr,
+                             const float* beta2 = nullptr) {
     using P = PoolTile<TA, S>;
-    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    const int nset = w2 ? 2 : 1;
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S, false>),
@@ -474,7 +483,8 @@ static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const fl
         attr_done = true;
     }
     hipLaunchKernelGGL((pool_tiled_kernel<TA, S, false>), grid, dim3(P::NT), P::SMEM, st, (const TA*)qkv, ld, chan_off, w, gamma,
-                       beta, (TA*)out, (const TA*)xhat, rstd, heads, T, H, W, Ho, Wo, eps);
+                       beta, (TA*)out, (const TA*)xhat, rstd, heads, T, H, W, Ho, Wo, eps, (int64_t)0, 0, 1, nset == 2 ? B * heads : 0, w2,
+                       gamma2, beta2);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -508,7 +518,7 @@ static int launch_pool_tiled_bwd(const void* qkv, int64_t ld, int chan_off, cons
 template <typename TA, int S>
 __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel(
     const TA* __restrict__ qkv, int64_t ld, int chan_off, const TA* __restrict__ dconv, float* __restrict__ part, int heads,
-    int T, int H, int W, int Ho, int Wo) {
+    int T, int H, int W, int Ho, int Wo, int set_bh = 0) {
     using P = PoolTile<TA, S>;
     constexpr int DT_BYTES = P::NTOK * 96 * (int)sizeof(TA);     // one d_conv frame tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -518,10 +528,11 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
     const int cp = tid % 48, row = tid / 48;
     const int tiles_x = (Wo + P::XO - 1) / P::XO;
     const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
-    const int bh = blockIdx.y;
-    const int b = bh / heads, g = bh - b * heads;
+    const int bh = blockIdx.y;                  // set_bh > 0: two tensors (see pool_tiled_kernel), set-major -> each set's partial rows are contiguous
+    const int hoff = (set_bh > 0 && bh >= set_bh) ? heads : 0, bhs = hoff ? bh - set_bh : bh;
+    const int b = bhs / heads, g = bhs - b * heads;
     const int64_t Nin = (int64_t)T * H * W;
-    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + g * 96;
+    const TA* base = qkv + (int64_t)b * Nin * ld + chan_off + (hoff + g) * 96;
     const TA* dbase = dconv + (int64_t)bh * T * Ho * Wo * 96;
     const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
     constexpr int CW = P::CW;
@@ -686,11 +697,11 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 2) void pool_wgrad_tiled_kernel
 
 template <typename TA, int S>
 static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
-                                   int T, int H, int W, int Ho, int Wo, hipStream_t st) {
+                                   int T, int H, int W, int Ho, int Wo, hipStream_t st, int nset = 1) {
     using P = PoolTile<TA, S>;
     constexpr int SM = P::IN_BYTES + 3 * P::NTOK * 96 * (int)sizeof(TA);
     static_assert(SM >= 2592 * 4, "partial row must fit");
-    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_tiled_kernel<TA, S>),
@@ -701,7 +712,7 @@ static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
     // (a gridDim.z split of the frames is supported by the kernel but measured slower here: the prologue and the LDS reduction of
     // the 2592 partial sums are paid per workgroup)
     hipLaunchKernelGGL((pool_wgrad_tiled_kernel<TA, S>), grid, dim3(P::NT), SM, st, (const TA*)qkv, ld, chan_off, (const TA*)dconv,
-                       part, heads, T, H, W, Ho, Wo);
+                       part, heads, T, H, W, Ho, Wo, nset == 2 ? B * heads : 0);
     MVIT_LAUNCH_CHECK();
     return (int)(grid.x * grid.y * grid.z);
 }
@@ -731,7 +742,8 @@ struct Dgrad2Tile {
 template <typename TA>
 __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __restrict__ dconv, const float* __restrict__ w,
                                                                    TA* __restrict__ dqkv, int64_t ld, int chan_off, int heads, int T,
-                                                                   int H, int W, int Ho, int Wo) {
+                                                                   int H, int W, int Ho, int Wo, int set_bh = 0,
+                                                                   const float* __restrict__ w2 = nullptr) {
     using P = Dgrad2Tile<TA>;
     constexpr int CW = P::CW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -742,8 +754,10 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
     const int cp = tid % 48, row = tid / 48;
     const int tiles_x = (Wo + P::XO - 1) / P::XO;
     const int xo0 = (blockIdx.x % tiles_x) * P::XO, yo0 = (blockIdx.x / tiles_x) * P::ROWS;
-    const int bh = blockIdx.y;
-    const int b = bh / heads, g = bh - b * heads;
+    const int bh = blockIdx.y;                  // set_bh > 0: two tensors in one launch (see pool_tiled_kernel)
+    int bhs = bh, hoff = 0;
+    if (set_bh > 0 && bh >= set_bh) { bhs = bh - set_bh; hoff = heads; w = w2; }
+    const int b = bhs / heads, g = hoff + (bhs - b * heads);          // g: head index inside the fused buffer's channel slice
     const TA* dbase = dconv + (int64_t)bh * T * Ho * Wo * 96;
     for (int i = tid; i < 27 * 96; i += P::NT) {
         const int tap = i / 96, c = i - tap * 96;
@@ -851,9 +865,10 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
 
 template <typename TA>
 static int launch_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
-                                    int H, int W, int Ho, int Wo, hipStream_t st) {
+                                    int H, int W, int Ho, int Wo, hipStream_t st, const float* w2 = nullptr) {
     using P = Dgrad2Tile<TA>;
-    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    const int nset = w2 ? 2 : 1;
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_dgrad2_tiled_kernel<TA>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -863,7 +878,7 @@ static int launch_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqk
     }
     if (grid.x * grid.y * 2 <= 512 && T >= 4) grid.z = 2;        // small grids: split the frames to fill the chip
     hipLaunchKernelGGL((pool_dgrad2_tiled_kernel<TA>), grid, dim3(P::NT), P::SMEM, st, (const TA*)dconv, w, (TA*)dqkv, ld, chan_off, heads,
-                       T, H, W, Ho, Wo);
+                       T, H, W, Ho, Wo, nset == 2 ? B * heads : 0, w2);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -910,6 +925,20 @@ int mvit_internal_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv
 }
 
 // internal: returns the number of [2592]-float partial rows written, or a negative error (strides 1 and 2 only)
+// the k and v tensors of a block in one launch each (stride 2; dconv / outputs of the two sets back to back, see pool_tiled_kernel)
+int mvit_internal_pool_dgrad2_tiled_kv(const void* dconv_kv, const float* w_k, const float* w_v, void* dqkv, int64_t ld, int chan_off_k,
+                                       int B, int heads, int T, int H, int W, int act_dtype, hipStream_t st) {
+    if ((int64_t)2 * B * heads > 65535) return MVIT_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return act_dtype == MVIT_BF16 ? launch_pool_dgrad2_tiled<bf16_t>(dconv_kv, w_k, dqkv, ld, chan_off_k, B, heads, T, H, W, Ho, Wo, st, w_v)
+                                  : launch_pool_dgrad2_tiled<float>(dconv_kv, w_k, dqkv, ld, chan_off_k, B, heads, T, H, W, Ho, Wo, st, w_v);
+}
+int mvit_internal_pool_wgrad_tiled_kv(const void* qkv, int64_t ld, int chan_off_k, const void* dconv_kv, float* part, int B, int heads,
+                                      int T, int H, int W, int act_dtype, hipStream_t st) {       // returns the partial rows of BOTH sets
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return act_dtype == MVIT_BF16 ? launch_pool_wgrad_tiled<bf16_t, 2>(qkv, ld, chan_off_k, dconv_kv, part, B, heads, T, H, W, Ho, Wo, st, 2)
+                                  : launch_pool_wgrad_tiled<float, 2>(qkv, ld, chan_off_k, dconv_kv, part, B, heads, T, H, W, Ho, Wo, st, 2);
+}
 int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st) {
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
@@ -989,6 +1018,29 @@ extern "C" int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan
         return MVIT_EDTYPE;
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
+}
+
+
+// k and v pooling conv + LayerNorm of a block in ONE launch (stride 2 only; other strides: MVIT_EUNSUPPORTED, call the single form
+// twice).  The v head group follows the k group in the fused qkv buffer (chan_off_k + heads * 96); out_kv / xhat_kv are
+// [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv [2][B*heads*T*Ho*Wo].
+extern "C" int mvit_pool_conv_ln_fwd_train_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
+                                              const float* beta_k, const float* w_v, const float* gamma_v, const float* beta_v,
+                                              void* out_kv, void* xhat_kv, float* rstd_kv, int B, int heads, int T, int H, int W,
+                                              int stride_hw, float eps, int act_dtype, void* stream) {
+    if (!qkv || !w_k || !gamma_k || !beta_k || !w_v || !gamma_v || !beta_v || !out_kv || B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0)
+        return MVIT_EINVAL;
+    if ((xhat_kv == nullptr) != (rstd_kv == nullptr)) return MVIT_EINVAL;
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if ((ld & 7) || (chan_off_k & 7)) return MVIT_EUNSUPPORTED;
+    if (stride_hw != 2 || (int64_t)2 * B * heads > 65535) return MVIT_EUNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipStream_t st = as_stream(stream);
+    if (act_dtype == MVIT_BF16)
+        return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off_k, w_k, gamma_k, beta_k, out_kv, xhat_kv, rstd_kv, B, heads, T, H, W, Ho, Wo, eps, st,
+                                            w_v, gamma_v, beta_v);
+    return launch_pool_tiled<float, 2>(qkv, ld, chan_off_k, w_k, gamma_k, beta_k, out_kv, xhat_kv, rstd_kv, B, heads, T, H, W, Ho, Wo, eps, st, w_v,
+                                       gamma_v, beta_v);
 }
 
 extern "C" int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,

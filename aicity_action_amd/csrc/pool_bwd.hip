@@ -17,6 +17,10 @@ int mvit_internal_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqk
                                     int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st);
+int mvit_internal_pool_dgrad2_tiled_kv(const void* dconv_kv, const float* w_k, const float* w_v, void* dqkv, int64_t ld, int chan_off_k,
+                                       int B, int heads, int T, int H, int W, int act_dtype, hipStream_t st);
+int mvit_internal_pool_wgrad_tiled_kv(const void* qkv, int64_t ld, int chan_off_k, const void* dconv_kv, float* part, int B, int heads,
+                                      int T, int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
                                     void* dconv, float* part, int B, int heads, int T, int H, int W, int stride_hw, float eps,
                                     int act_dtype, hipStream_t st);
@@ -421,10 +425,16 @@ __global__ __launch_bounds__(256) void pool_dgrad_sparse_kernel(const TA* __rest
 template <typename TA>
 __global__ __launch_bounds__(256) void pool_ln_bwd_saved_kernel(const TA* __restrict__ xhat, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const TA* __restrict__ dout,
-                                                                TA* __restrict__ dconv, float* __restrict__ part, int64_t total) {
+                                                                TA* __restrict__ dconv, float* __restrict__ part, int64_t total,
+                                                                const float* __restrict__ gamma2 = nullptr) {
     constexpr int CW = 16 / sizeof(TA);
     constexpr int NCH = 24 / CW;
     __shared__ float red[4][192];        // one row per wave, added in wave order below (LDS float atomics would sum in arrival order)
+    if (blockIdx.y == 1) {               // second tensor of a two-tensor launch (k / v pair): `total` tokens further on, own gamma
+        xhat += total * 96; dout += total * 96; dconv += total * 96; rstd += total;
+        gamma = gamma2;
+        part += (int64_t)gridDim.x * 192;
+    }
     const int j = threadIdx.x & 3;
     float g[24], dg[24], db[24];
 #pragma unroll
@@ -596,6 +606,50 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     if (act_dtype == MVIT_F32) { RUN(float) } else { RUN(bf16_t) }
 #undef RUN
     return MVIT_OK;
+}
+
+// Backward of the k and v pooling convs of a block together (stride 2, saved xhat / rstd; other cases: MVIT_EUNSUPPORTED, use the
+// single form twice): three launches for both tensors -- LayerNorm backward, conv weight gradient, conv data gradient -- each with
+// twice the workgroups of the single form (which at 256 workgroups of 3 waves is latency-bound).  xhat_kv / dout_kv / dconv_kv are
+// [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv [2][...]; workspace >= 2 x mvit_pool_bwd_workspace_bytes2(...).  The per-tensor
+// sums (d_w, d_gamma, d_beta) are reduced over each tensor's own contiguous partial rows: bit-identical to the single form.
+extern "C" int mvit_pool_conv_ln_bwd_saved_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
+                                              const float* w_v, const float* gamma_v, const void* xhat_kv, const float* rstd_kv,
+                                              const void* dout_kv, void* dconv_kv, void* dqkv, float* dw_k, float* dgamma_k, float* dbeta_k,
+                                              float* dw_v, float* dgamma_v, float* dbeta_v, int accumulate_param, float* workspace, int B,
+                                              int heads, int T, int H, int W, int stride_hw, int act_dtype, void* stream) {
+    if (!qkv || !w_k || !gamma_k || !w_v || !gamma_v || !xhat_kv || !rstd_kv || !dout_kv || !dconv_kv || !dqkv || !dw_k || !dgamma_k ||
+        !dbeta_k || !dw_v || !dgamma_v || !dbeta_v || !workspace || B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0)
+        return MVIT_EINVAL;
+    if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
+    if ((ld & 7) || (chan_off_k & 7)) return MVIT_EUNSUPPORTED;
+    if (stride_hw != 2 || (int64_t)2 * B * heads > 65535) return MVIT_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t tot_out = (int64_t)B * heads * T * Ho * Wo;            // tokens of ONE tensor
+    int64_t prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;   // rows of mvit_pool_bwd_workspace_bytes2, per tensor
+    if (prow < PB_MAXBLK) prow = PB_MAXBLK;
+    int64_t bs = (tot_out + 63) / 64;
+    bs = bs > prow ? prow : bs;
+    bs = bs > 2048 ? 2048 : bs;
+    float* wpart = workspace + 2 * prow * 192;
+#define RUNKV(TA)                                                                                                                  \
+    hipLaunchKernelGGL((pool_ln_bwd_saved_kernel<TA>), dim3((unsigned)bs, 2), dim3(256), 0, st, (const TA*)xhat_kv, rstd_kv, gamma_k, \
+                       (const TA*)dout_kv, (TA*)dconv_kv, workspace, tot_out, gamma_v);                                            \
+    MVIT_LAUNCH_CHECK();
+    if (act_dtype == MVIT_F32) { RUNKV(float) } else { RUNKV(bf16_t) }
+#undef RUNKV
+    int rc = launch_pool_reduce(workspace, (int)bs, 192, dgamma_k, dbeta_k, 96, accumulate_param, st, 1);
+    if (rc != MVIT_OK) return rc;
+    rc = launch_pool_reduce(workspace + bs * 192, (int)bs, 192, dgamma_v, dbeta_v, 96, accumulate_param, st, 1);
+    if (rc != MVIT_OK) return rc;
+    const int wr = mvit_internal_pool_wgrad_tiled_kv(qkv, ld, chan_off_k, dconv_kv, wpart, B, heads, T, H, W, act_dtype, st);
+    if (wr < 0) return wr;
+    rc = launch_pool_reduce(wpart, wr / 2, 2592, dw_k, dw_k, 2592, 1, st, 1);
+    if (rc != MVIT_OK) return rc;
+    rc = launch_pool_reduce(wpart + (int64_t)(wr / 2) * 2592, wr / 2, 2592, dw_v, dw_v, 2592, 1, st, 1);
+    if (rc != MVIT_OK) return rc;
+    return mvit_internal_pool_dgrad2_tiled_kv(dconv_kv, w_k, w_v, dqkv, ld, chan_off_k, B, heads, T, H, W, act_dtype, st);
 }
 
 extern "C" int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,

@@ -209,6 +209,23 @@ int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan_off, const
                                 float* dbeta, int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
                                 int stride_hw, float eps, int act_dtype, void* stream);
 
+/* The k and the v pooling conv (+ LayerNorm) of a block in ONE set of launches (attention.py:196-213: pool_k / norm_k and pool_v /
+ * norm_v read adjacent head groups of the same fused qkv buffer -- channel offsets chan_off_k and chan_off_k + heads*96 -- with the
+ * same geometry).  Spatial stride 2 only (the eleven blocks whose k / v grid is half the token grid); any other stride returns
+ * MVIT_EUNSUPPORTED and the caller uses the single-tensor form twice.  Tensors of the pair are laid out back to back:
+ * out_kv / xhat_kv / dout_kv / dconv_kv = [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv = [2][B*heads*T*Ho*Wo].  The backward
+ * needs workspace >= 2 * mvit_pool_bwd_workspace_bytes2(B, heads, T, H, W, 2).  Results are bit-identical to the single form
+ * (each tensor's partial sums are reduced over its own rows, in the same order). */
+int mvit_pool_conv_ln_fwd_train_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
+                                   const float* beta_k, const float* w_v, const float* gamma_v, const float* beta_v, void* out_kv,
+                                   void* xhat_kv, float* rstd_kv, int B, int heads, int T, int H, int W, int stride_hw, float eps,
+                                   int act_dtype, void* stream);
+int mvit_pool_conv_ln_bwd_saved_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
+                                   const float* w_v, const float* gamma_v, const void* xhat_kv, const float* rstd_kv,
+                                   const void* dout_kv, void* dconv_kv, void* dqkv, float* dw_k, float* dgamma_k, float* dbeta_k,
+                                   float* dw_v, float* dgamma_v, float* dbeta_v, int accumulate_param, float* workspace, int B,
+                                   int heads, int T, int H, int W, int stride_hw, int act_dtype, void* stream);
+
 /* Backward of mvit_maxpool_skip_fwd: gradient goes to the first maximum of each window (ATen semantics). */
 int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
 

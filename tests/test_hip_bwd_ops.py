@@ -507,3 +507,58 @@ def test_adamw_step_dev_equals_adamw_step(hip_lib):
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
+@pytest.mark.parametrize("B,h,T,H,W", [(2, 2, 3, 14, 14), (1, 4, 4, 28, 28), (3, 1, 2, 10, 18)])
+def test_pool_kv_pair_form_equals_two_single_calls(hip_lib, act, B, h, T, H, W):
+    """mvit_pool_conv_ln_fwd_train_kv / _bwd_saved_kv (k and v of a block in one set of launches, stride 2): every output is bit for
+    bit what the single-tensor entry points give."""
+    s = 2
+    C = 96 * h
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    L = T * Ho * Wo
+    dt = torch.float32 if act == _hip.F32 else torch.bfloat16
+    qkv = _rnd(B, T * H * W, 3 * C, seed=81).to(dt).to(DEV)
+    par = [((_rnd(96, 27, seed=82 + i) * 0.2).to(DEV), (1 + 0.1 * _rnd(96, seed=84 + i)).to(DEV), (0.1 * _rnd(96, seed=86 + i)).to(DEV)) for i in range(2)]
+    # ---- forward
+    kv = torch.empty(2, B, h, L, 96, dtype=dt, device=DEV)
+    xh = torch.empty_like(kv)
+    rs = torch.empty(2, B * h * L, device=DEV)
+    _hip.check(hip_lib.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * C, C, _hip.ptr(par[0][0]), _hip.ptr(par[0][1]), _hip.ptr(par[0][2]),
+                                                      _hip.ptr(par[1][0]), _hip.ptr(par[1][1]), _hip.ptr(par[1][2]), _hip.ptr(kv), _hip.ptr(xh),
+                                                      _hip.ptr(rs), B, h, T, H, W, s, 1e-5, act, _st()))
+    for i in range(2):
+        o1 = torch.empty(B, h, L, 96, dtype=dt, device=DEV)
+        x1 = torch.empty_like(o1)
+        r1 = torch.empty(B * h * L, device=DEV)
+        _hip.check(hip_lib.mvit_pool_conv_ln_fwd_train(_hip.ptr(qkv), 3 * C, (1 + i) * C, _hip.ptr(par[i][0]), _hip.ptr(par[i][1]), _hip.ptr(par[i][2]),
+                                                       _hip.ptr(o1), _hip.ptr(x1), _hip.ptr(r1), B, h, T, H, W, s, 1e-5, act, _st()))
+        assert torch.equal(kv[i], o1) and torch.equal(xh[i], x1) and torch.equal(rs[i], r1)
+    # ---- backward
+    dkv = _rnd(2, B, h, L, 96, seed=90).to(dt).to(DEV)
+    nb = hip_lib.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, s)
+    dconv = torch.empty_like(dkv)
+    dqkv = torch.zeros_like(qkv)
+    g = [[torch.zeros(96, 27, device=DEV), torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)] for _ in range(2)]
+    ws = torch.empty(2 * nb // 4, device=DEV)
+    _hip.check(hip_lib.mvit_pool_conv_ln_bwd_saved_kv(_hip.ptr(qkv), 3 * C, C, _hip.ptr(par[0][0]), _hip.ptr(par[0][1]), _hip.ptr(par[1][0]),
+                                                      _hip.ptr(par[1][1]), _hip.ptr(xh), _hip.ptr(rs), _hip.ptr(dkv), _hip.ptr(dconv), _hip.ptr(dqkv),
+                                                      _hip.ptr(g[0][0]), _hip.ptr(g[0][1]), _hip.ptr(g[0][2]), _hip.ptr(g[1][0]), _hip.ptr(g[1][1]),
+                                                      _hip.ptr(g[1][2]), 1, _hip.ptr(ws), B, h, T, H, W, s, act, _st()))
+    dqkv1 = torch.zeros_like(qkv)
+    for i in range(2):
+        dc1 = torch.empty(B, h, L, 96, dtype=dt, device=DEV)
+        g1 = [torch.zeros(96, 27, device=DEV), torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)]
+        ws1 = torch.empty(nb // 4, device=DEV)
+        _hip.check(hip_lib.mvit_pool_conv_ln_bwd_saved(_hip.ptr(qkv), 3 * C, (1 + i) * C, _hip.ptr(par[i][0]), _hip.ptr(par[i][1]), _hip.ptr(xh[i]),
+                                                       _hip.ptr(rs[i]), _hip.ptr(dkv[i]), _hip.ptr(dc1), _hip.ptr(dqkv1), _hip.ptr(g1[0]), _hip.ptr(g1[1]),
+                                                       _hip.ptr(g1[2]), 1, _hip.ptr(ws1), B, h, T, H, W, s, 1e-5, act, _st()))
+        assert torch.equal(dconv[i], dc1)
+        for a, b in zip(g[i], g1):
+            assert torch.equal(a, b)
+    assert torch.equal(dqkv, dqkv1)
+    # other strides are refused (the caller falls back to the single form)
+    assert hip_lib.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * C, C, _hip.ptr(par[0][0]), _hip.ptr(par[0][1]), _hip.ptr(par[0][2]),
+                                                  _hip.ptr(par[1][0]), _hip.ptr(par[1][1]), _hip.ptr(par[1][2]), _hip.ptr(kv), _hip.ptr(xh),
+                                                  _hip.ptr(rs), B, h, T, H, W, 1, 1e-5, act, _st()) != 0
