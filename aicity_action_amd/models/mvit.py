@@ -12,6 +12,7 @@ There is no eager/CPU fallback: calling forward without a gfx950 device or witho
 library raises.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -399,9 +400,10 @@ class MViT(nn.Module):
         Tk, Hk, Wk = g.thw_kv
         Lq, Lk = g.lq, g.lk
         q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
-        k = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        v = torch.empty(B, h, Lk, 96, dtype=adt, device=dev)
-        pools = [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
+        kv = torch.empty(2, B, h, Lk, 96, dtype=adt, device=dev)      # k and v back to back (the pair form of the pooling kernel)
+        k, v = kv[0], kv[1]
+        kv_batch = g.stride_kv[1] == 2 and os.environ.get("MVIT_POOL_KV_BATCH", "1") != "0"
+        pools = [] if kv_batch else [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
         if g.kernel_q:
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:       # pool_q is None (Q_POOL_ALL off): the query is the head-split slice itself, no LayerNorm (attention.py:14-15)
@@ -413,6 +415,11 @@ class MViT(nn.Module):
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight),
                                                _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W,
                                                stride, norm.eps, act, st if which == 0 else side), "pool%d" % which)
+        if kv_batch:      # k and v pooling conv + LayerNorm in one launch (no saved statistics in inference)
+            _hip.check(L.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * Cout, Cout, _hip.ptr(at.pool_k.weight), _hip.ptr(at.norm_k.weight),
+                                                        _hip.ptr(at.norm_k.bias), _hip.ptr(at.pool_v.weight), _hip.ptr(at.norm_v.weight),
+                                                        _hip.ptr(at.norm_v.bias), _hip.ptr(kv), None, None, B, h, T, H, W, g.stride_kv[1],
+                                                        at.norm_k.eps, act, side), "pool_kv")
         if forked:
             _hip.check(L.mvit_side_join(st), "side_join")
         del qkv
