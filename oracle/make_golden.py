@@ -47,6 +47,8 @@ CASES = {
     "tiny_plain": ("MVITV2_B_16x4_CONV.yaml", dict(TINY, **{"DATA.TRAIN_CROP_SIZE": 64, "DATA.TEST_CROP_SIZE": 64}), 2, 13),
     "full224": ("MVITV2_FULL_B_16x4_CONV.yaml", {}, 1, 1),
     "full448": ("MVITV2_FULL_B_16x4_CONV_448.yaml", {}, 1, 2),
+    # the depth-24 32x3 variant (T' = 16, stage transitions at blocks 2 / 5 / 21), forward only
+    "v32x3_224": ("MVITV2_FULL_B_32x3_CONV.yaml", {}, 1, 9),
 }
 
 

@@ -32,7 +32,7 @@ def _build(meta, precision):
     return cfg, model
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448", "v32x3_224"])
 def test_fp32_forward_matches_reference_golden(name):
     z, meta = load_golden(name)
     cfg, model = _build(meta, "fp32")
@@ -54,7 +54,7 @@ def test_fp32_forward_matches_reference_golden(name):
         assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448", "v32x3_224"])
 def test_bf16_forward_vs_reference_golden(name):
     z, meta = load_golden(name)
     cfg, model = _build(meta, "bf16")
@@ -67,7 +67,7 @@ def test_bf16_forward_vs_reference_golden(name):
     assert dl <= BF16_LOGIT_TOL and dp <= BF16_PROB_TOL
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "full448", "v32x3_224"])
 def test_fp16_mfma_forward_meets_the_1e3_logit_gate(name):
     """Same MFMA kernels built with the 16-bit type = IEEE half (libmvit_hip_f16.so): 3 more mantissa bits than bf16 at the
     same MFMA rate -> the north-star 1e-3 logit gate holds on a matrix-core path."""

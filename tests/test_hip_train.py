@@ -144,7 +144,7 @@ def _full_train_step(name, precision):
     return z, meta, model, logits.detach(), loss.item(), grads, out2[0].item(), out2[1].item()
 
 
-@pytest.mark.parametrize("name", ["full224", "full448"])
+@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224"])
 def test_full_size_fp32_train_step_matches_reference_golden(name):
     """BASELINE configs[0] / configs[2] geometry (16 blocks, real token counts), B=1, exact-fp32 kernels: loss 1e-5, gradient
     norm, every parameter's gradient samples <= 1e-4 relative, parameters after the clipped AdamW step."""
@@ -181,7 +181,7 @@ def test_full_size_fp32_train_step_matches_reference_golden(name):
     assert worst_own <= 2e-3, (worst_own_name, worst_own)
 
 
-@pytest.mark.parametrize("name", ["full224", "full448"])
+@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224"])
 def test_full_size_bf16_train_step_vs_reference_golden(name):
     """The benchmarked precision at the benchmarked geometry (configs[2] @448): the bf16 MFMA forward + hand-written backward
     against the reference's fp32 train step.  Bounds: loss 2e-2, global |g| within 3 %, cosine of the sampled gradient vector
