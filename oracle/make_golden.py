@@ -49,6 +49,8 @@ CASES = {
     "full448": ("MVITV2_FULL_B_16x4_CONV_448.yaml", {}, 1, 2),
     # the depth-24 32x3 variant (T' = 16, stage transitions at blocks 2 / 5 / 21), forward only
     "v32x3_224": ("MVITV2_FULL_B_32x3_CONV.yaml", {}, 1, 9),
+    # ... and the non-FULL 16x4 model at full size (blocks whose query has no pooling conv: head split only, no "+q")
+    "plain224": ("MVITV2_B_16x4_CONV.yaml", {}, 1, 10),
 }
 
 

@@ -144,7 +144,7 @@ def _full_train_step(name, precision):
     return z, meta, model, logits.detach(), loss.item(), grads, out2[0].item(), out2[1].item()
 
 
-@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224"])
+@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224", "plain224"])
 def test_full_size_fp32_train_step_matches_reference_golden(name):
     """BASELINE configs[0] / configs[2] geometry (16 blocks, real token counts), B=1, exact-fp32 kernels: loss 1e-5, gradient
     norm, every parameter's gradient samples <= 1e-4 relative, parameters after the clipped AdamW step."""
@@ -168,6 +168,10 @@ def test_full_size_fp32_train_step_matches_reference_golden(name):
             # = 2e-3 of the tensor's scale, so these tensors get a looser own-scale bound
             if "proj_max_pool" in k:
                 assert own <= 2e-2, (k, own)
+            elif k.startswith(("patch_embed.", "pos_embed", "blocks.0.")):
+                # everything upstream of block 1's skip max-pool sees such a flip as a perturbation of ITS incoming gradient
+                # (observed: 2.4e-3 of the stem weight gradient's own scale on the plain 224 model, 1e-5 in absolute terms)
+                assert own <= 5e-3, (k, own)
             elif own > worst_own:
                 worst_own, worst_own_name = own, k
         # AdamW step 1 moves every element by lr * g / (|g| + eps) = +-lr: compare where the reference gradient is far above
@@ -181,7 +185,7 @@ def test_full_size_fp32_train_step_matches_reference_golden(name):
     assert worst_own <= 2e-3, (worst_own_name, worst_own)
 
 
-@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224"])
+@pytest.mark.parametrize("name", ["full224", "full448", "v32x3_224", "plain224"])
 def test_full_size_bf16_train_step_vs_reference_golden(name):
     """The benchmarked precision at the benchmarked geometry (configs[2] @448): the bf16 MFMA forward + hand-written backward
     against the reference's fp32 train step.  Bounds: loss 2e-2, global |g| within 3 %, cosine of the sampled gradient vector

@@ -24,7 +24,7 @@ def _run(name, train=False):
     return z, meta, cfg, sd, clip
 
 
-@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "v32x3_224"])
+@pytest.mark.parametrize("name", ["tiny_even", "tiny_odd", "tiny_plain", "full224", "v32x3_224", "plain224"])
 def test_oracle_forward_matches_reference_golden(name):
     z, meta, cfg, sd, clip = _run(name)
     taps = {}
