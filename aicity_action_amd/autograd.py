@@ -467,7 +467,15 @@ class _BlockFn(torch.autograd.Function):
             extra = [dWm, dbm]
         else:
             d_x = d_r
-        if ctx.prev_dp2 is not None:      # d_x is the upstream block's incoming gradient: cast it for that block's fc2 GEMMs right here
+        ln1_base = None
+        if act == _hip.F32 and d_x is d_y:
+            # exact-fp32 path: the proj weight-gradient GEMM on the side stream reads d_y ITSELF (no 16-bit copy of it exists), so the
+            # LayerNorm backward must not accumulate into it in place -- under load the side stream can still be reading when this
+            # stream gets here (seen as one wrong blocks.0.attn.proj.weight gradient in ~1 of 10 runs of the two-rank test)
+            ln1_base, d_x = d_y, torch.empty_like(d_y)
+        if ln1_base is not None:
+            dg1, dbe1 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, False, base=ln1_base)
+        elif ctx.prev_dp2 is not None:    # d_x is the upstream block's incoming gradient: cast it for that block's fc2 GEMMs right here
             dg1, dbe1, x16 = hx.ln_bwd(x2, blk.norm1, d_u, d_x, True, emit16=(ctx.prev_dp2[0], N))
             if x16 is not None:
                 hx._g16_stash = (d_x.data_ptr(), x16)
