@@ -278,43 +278,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const uint32_t so = (uint32_t)(stage * BQ_TILEB);
         stage = stage == BQ_STAGES - 1 ? 0 : stage + 1;
 
+        // One tile = four phases; inside a wave the dS arithmetic of one 32-key half runs in the gaps between the MFMAs of the
+        // other half (MFMA 32 cycles on the matrix pipe, ~8 VALU issues behind each):
+        //   A  S^T / dP^T of keys 0..31                          (12 MFMA)
+        //   B  S^T / dP^T of keys 32..63  ||  dS of keys 0..31   (12 MFMA, 16 elements)
+        //   C  dQ^T += K^T dS^T, keys 0..31  ||  dS of keys 32..63 (6 MFMA, 16 elements)
+        //   D  dQ^T += K^T dS^T, keys 32..63                     (6 MFMA)
+        // (tile by tile -- 24 MFMA, then all the dS arithmetic, then 12 MFMA -- the matrix pipe idled under 190 VALU instructions
+        // and the VALU under 36 MFMAs.)  Keys past Lk (last tile): their score accumulators START at -inf, so P = exp2(-inf) = 0
+        // and dS = 0 without a mask in the arithmetic.
+        const int kbase = kt * B_T;
         f32x16 s[2], dp[2];
+        if (kbase + B_T > Lk) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
-        // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order).  Left to
-        // the compiler this phase was eleven rounds of {2 ds_read_b128; s_waitcnt lgkmcnt(0); 2 MFMA}: the LDS latency of every
-        // round exposed
-        bf16x8 kf[3][2], vf[3][2];
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    s[kb][i] = key < Lk ? 0.f : -INFINITY;
+                    dp[kb][i] = 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+        }
+        // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order)
+        bf16x8 kf[3], vf[3];
         const uint32_t fa0 = ka0 + so, fa4 = ka4 + so, fa5 = ka5 + so;
-#define DQ_RD(SL, A, OFF) { kf[SL][0] = b_rd128<OFF>(A); vf[SL][0] = b_rd128<OFF + B_T * B_ROWB>(A); \
-                            kf[SL][1] = b_rd128<OFF + 32 * B_ROWB>(A); vf[SL][1] = b_rd128<OFF + B_T * B_ROWB + 32 * B_ROWB>(A); }
-#define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(kf[SL][0]), "+v"(vf[SL][0]), "+v"(kf[SL][1]), "+v"(vf[SL][1]) : "n"(N))
-#define DQ_MM(SL, KS) { s[0] = mfma16(kf[SL][0], qf[KS], s[0]); dp[0] = mfma16(vf[SL][0], dof[KS], dp[0]); \
-                        s[1] = mfma16(kf[SL][1], qf[KS], s[1]); dp[1] = mfma16(vf[SL][1], dof[KS], dp[1]); }
-        DQ_RD(0, fa0, 0) DQ_RD(1, fa0, 32)
-        DQ_WAIT(0, 4);
-        DQ_RD(2, fa0, 64)
-        DQ_MM(0, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        DQ_WAIT(1, 4);
-        DQ_RD(0, fa0, 96)
-        DQ_MM(1, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        DQ_WAIT(2, 4);
-        DQ_RD(1, fa4, 0)
-        DQ_MM(2, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        DQ_WAIT(0, 4);
-        DQ_RD(2, fa5, 0)
-        DQ_MM(0, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        DQ_WAIT(1, 4);
-        DQ_MM(1, 4)
-        __builtin_amdgcn_sched_barrier(0);
-        // K^T fragments of the first two 16-key steps: requested now, they land under the dS arithmetic
-        bf16x4 ta[12];
+        float dsv[2][16];
+        bf16x8 dsf[4];
+        bf16x4 ta[12], tb[12];
+#define DQ_RD(SL, A, OFF, KB) { kf[SL] = b_rd128<OFF + (KB) * 32 * B_ROWB>(A); vf[SL] = b_rd128<OFF + B_T * B_ROWB + (KB) * 32 * B_ROWB>(A); }
+#define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[SL]), "+v"(vf[SL]) : "n"(N))
+#define DQ_MM(SL, KS, KB) { s[KB] = mfma16(kf[SL], qf[KS], s[KB]); dp[KB] = mfma16(vf[SL], dof[KS], dp[KB]); }
+#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(fmaf(s[KB][I], scale_log2e, -lse)); dsv[KB][I] = p_ * (dp[KB][I] - dlt); }
+#define DQ_SB __builtin_amdgcn_sched_barrier(0);
 #define TRQ(A, S16) \
         A[0] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[0] + so); A[1] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[0] + so); \
         A[2] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[1] + so); A[3] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[1] + so); \
@@ -322,53 +322,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         A[6] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[0] + so); A[7] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[0] + so); \
         A[8] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[1] + so); A[9] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[1] + so); \
         A[10] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_lo[2] + so); A[11] = b_tr16<(S16 + 1) * 16 * B_ROWB>(t_hi[2] + so);
-        TRQ(ta, 0)
-        DQ_WAIT(2, 12);       // the twelve transposing reads just issued stay in flight under these MFMAs and the dS arithmetic
-        DQ_MM(2, 5)
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- A
+        DQ_RD(0, fa0, 0, 0) DQ_RD(1, fa0, 32, 0)
+        DQ_WAIT(0, 2); DQ_RD(2, fa0, 64, 0) DQ_MM(0, 0, 0) DQ_SB
+        DQ_WAIT(1, 2); DQ_RD(0, fa0, 96, 0) DQ_MM(1, 1, 0) DQ_SB
+        DQ_WAIT(2, 2); DQ_RD(1, fa4, 0, 0) DQ_MM(2, 2, 0) DQ_SB
+        DQ_WAIT(0, 2); DQ_RD(2, fa5, 0, 0) DQ_MM(0, 3, 0) DQ_SB
+        DQ_WAIT(1, 2); DQ_RD(0, fa0, 0, 1) DQ_MM(1, 4, 0) DQ_SB
+        DQ_WAIT(2, 2); DQ_RD(1, fa0, 32, 1) DQ_MM(2, 5, 0) DQ_SB
+        // ---- B
+        DQ_WAIT(0, 2); DQ_RD(2, fa0, 64, 1) DQ_MM(0, 0, 1) DQ_VAL(0, 0) DQ_VAL(0, 1) DQ_VAL(0, 2) DQ_SB
+        DQ_WAIT(1, 2); DQ_RD(0, fa0, 96, 1) DQ_MM(1, 1, 1) DQ_VAL(0, 3) DQ_VAL(0, 4) DQ_VAL(0, 5) DQ_SB
+        DQ_WAIT(2, 2); DQ_RD(1, fa4, 0, 1) DQ_MM(2, 2, 1) DQ_VAL(0, 6) DQ_VAL(0, 7) DQ_VAL(0, 8) DQ_SB
+        dsf[0] = pack8(&dsv[0][0]);
+        DQ_WAIT(0, 2); DQ_RD(2, fa5, 0, 1) DQ_MM(0, 3, 1) DQ_VAL(0, 9) DQ_VAL(0, 10) DQ_VAL(0, 11) DQ_SB
+        DQ_WAIT(1, 2);
+        TRQ(ta, 0)            // K^T fragments of keys 0..31: in flight under the rest of this phase
+        DQ_MM(1, 4, 1) DQ_VAL(0, 12) DQ_VAL(0, 13) DQ_SB
+        DQ_WAIT(2, 12); DQ_MM(2, 5, 1) DQ_VAL(0, 14) DQ_VAL(0, 15) DQ_SB
+        dsf[1] = pack8(&dsv[0][8]);
+        // ---- C
+        B_WAIT6(ta, 0);
+        TRQ(tb, 2)
+#define DQ_DQ(TT, S16, DB, E) dq[DB] = mfma16(b_join(TT[6 * (S16) + 2 * (DB)], TT[6 * (S16) + 2 * (DB) + 1]), dsf[E], dq[DB]);
+        DQ_DQ(ta, 0, 0, 0) DQ_VAL(1, 0) DQ_VAL(1, 1) DQ_VAL(1, 2) DQ_SB
+        DQ_DQ(ta, 0, 1, 0) DQ_VAL(1, 3) DQ_VAL(1, 4) DQ_VAL(1, 5) DQ_SB
+        DQ_DQ(ta, 0, 2, 0) DQ_VAL(1, 6) DQ_VAL(1, 7) DQ_VAL(1, 8) DQ_SB
+        dsf[2] = pack8(&dsv[1][0]);
+        DQ_DQ(ta, 1, 0, 1) DQ_VAL(1, 9) DQ_VAL(1, 10) DQ_VAL(1, 11) DQ_SB
+        DQ_DQ(ta, 1, 1, 1) DQ_VAL(1, 12) DQ_VAL(1, 13) DQ_SB
+        DQ_DQ(ta, 1, 2, 1) DQ_VAL(1, 14) DQ_VAL(1, 15) DQ_SB
+        dsf[3] = pack8(&dsv[1][8]);
+        // ---- D
+        B_WAIT6(tb, 0);
+        DQ_DQ(tb, 0, 0, 2) DQ_DQ(tb, 0, 1, 2) DQ_DQ(tb, 0, 2, 2)
+        DQ_DQ(tb, 1, 0, 3) DQ_DQ(tb, 1, 1, 3) DQ_DQ(tb, 1, 2, 3)
 #undef DQ_RD
 #undef DQ_WAIT
 #undef DQ_MM
-        const int kbase = kt * B_T;
-        const bool tail = kbase + B_T > Lk;
-        bf16x8 dsf[4];
-        // dS = P (dP - delta); the key mask of the tail tile lives in its own (wave-uniform) branch -- inside the unrolled loops
-        // the compiler if-converted it into a compare + two selects per element of EVERY tile (130 of 280 VALU instructions)
-        auto make_ds = [&](auto tail_tag) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    float dsv[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int i = 8 * sh + jj;
-                        float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], scale_log2e, -lse));
-                        if (decltype(tail_tag)::value) {
-                            const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            p = key < Lk ? p : 0.f;
-                        }
-                        dsv[jj] = p * (dp[kb][i] - dlt);
-                    }
-                    dsf[2 * kb + sh] = pack8(dsv);
-                }
-        };
-        if (tail) make_ds(std::true_type{});
-        else make_ds(std::false_type{});
-        // dQ^T += K^T . dS^T
-        bf16x4 tb[12];
-        B_WAIT6(ta, 0);
-        TRQ(tb, 2)
-#pragma unroll
-        for (int s16 = 0; s16 < 2; ++s16)
-#pragma unroll
-            for (int db = 0; db < 3; ++db) dq[db] = mfma16(b_join(ta[6 * s16 + 2 * db], ta[6 * s16 + 2 * db + 1]), dsf[s16], dq[db]);
-        __builtin_amdgcn_sched_barrier(0);
-        B_WAIT6(tb, 0);
-#pragma unroll
-        for (int s16 = 0; s16 < 2; ++s16)
-#pragma unroll
-            for (int db = 0; db < 3; ++db) dq[db] = mfma16(b_join(tb[6 * s16 + 2 * db], tb[6 * s16 + 2 * db + 1]), dsf[2 + s16], dq[db]);
+#undef DQ_VAL
+#undef DQ_SB
+#undef DQ_DQ
 #undef TRQ
     }
     if (q_ok) {
