@@ -325,21 +325,6 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, 
         store4(y + 4 * i, v);
     }
 }
-// 16-bit path: Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7) sharing its exponential with the density term -- one v_exp, one
-// v_rcp, ~18 VALU per element; libm erff + expf cost ~50 and made this bandwidth kernel VALU-bound
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-x^2/2)
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                        int64_t n4) {

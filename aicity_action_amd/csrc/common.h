@@ -112,6 +112,47 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one v_rcp;
+// libm erff costs 30-60 VALU instructions per element and made the fc1 epilogue VALU-bound.
+__device__ __forceinline__ float gelu_grad_fast(float x) {      // d/dx GELU_erf, same erf approximation, exponential shared
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
+}
+__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gval, float& gder) {     // GELU_erf(x) and its derivative, one exp + one rcp
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    const float cdf = 0.5f * (1.0f + erfv);
+    gval = x * cdf;
+    gder = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    const float erfv = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erfv);
+}
+
 // D = A(32x16) * B(16x32) + C on 16-bit operands held as raw bits (bf16x8 = 8 shorts); fp32 accumulate
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef MVIT_HALF_IS_FP16

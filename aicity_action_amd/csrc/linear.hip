@@ -10,6 +10,20 @@
 
 #include "common.h"
 
+// linear_pp.hip: the 256 x 192 ping-pong kernel (epilogue codes PP_*)
+bool mvit_internal_linear_pp_ok(int64_t lda, int64_t M, int N, int K);
+int mvit_internal_linear_pp(int epi, const void* a, int64_t lda, const void* w, const float* bias, const void* aux, int64_t ldaux,
+                            const float* row_scale, int64_t rps, void* y, void* y2, int64_t ldy, int64_t M, int N, int K, hipStream_t st);
+enum { PP_B16 = 0, PP_GELU16 = 1, PP_GELU_PRE = 2, PP_GELU_DER = 3, PP_F32 = 4, PP_F32_RES = 5, PP_F32_RES_SC = 6, PP_DG_PRE = 7, PP_DG_DER = 8 };
+// Which shapes go to it (MVIT_GEMM_PP=0 / 1 forces off / on for every shape it can take): measured per shape in profiles/r3_gemm_shapes.txt
+static inline bool use_pp(int64_t lda, int64_t M, int N, int K) {
+    static const char* env = getenv("MVIT_GEMM_PP");
+    if (env && env[0] == '0') return false;
+    if (!mvit_internal_linear_pp_ok(lda, M, N, K)) return false;
+    if (env && env[0] == '1') return true;
+    return M >= 8192;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA GEMM
 // ------------------------------------------------------------------------------------------------
@@ -46,47 +60,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
-}
-
-// fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one v_rcp;
-// libm erff costs 30-60 VALU instructions per element and made the fc1 epilogue VALU-bound.
-__device__ __forceinline__ float gelu_grad_fast(float x) {      // d/dx GELU_erf, same erf approximation, exponential shared
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
-}
-__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gval, float& gder) {     // GELU_erf(x) and its derivative, one exp + one rcp
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    const float cdf = 0.5f * (1.0f + erfv);
-    gval = x * cdf;
-    gder = fmaf(x * 0.39894228040143267794f, e, cdf);
-}
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erfv);
 }
 
 // Staging map: 16 lanes per row (12 carry a 16-byte chunk, 4 idle), rows tid/16 + 16*i.  The rotation
@@ -1185,6 +1158,18 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         return MVIT_EUNSUPPORTED;
 #define DISPATCH(TA, TO) \
     return launch_linear_mfma<TA, TO>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
+    if (a_dtype == MVIT_BF16 && (ldy & 7) == 0 && use_pp(lda, M, N, K)) {
+        const bool res = (epilogue & MVIT_EPI_RESIDUAL) != 0, gelu = (epilogue & MVIT_EPI_GELU) != 0;
+        int code = -1;
+        if (out_dtype == MVIT_BF16 && !res && !row_scale) code = gelu ? PP_GELU16 : PP_B16;
+        if (out_dtype == MVIT_F32 && !gelu) {
+            if (res && (ldr & 3) == 0) code = row_scale ? PP_F32_RES_SC : PP_F32_RES;
+            else if (!res && !row_scale) code = PP_F32;
+        }
+        if (code >= 0)
+            return mvit_internal_linear_pp(code, a, lda, w, (epilogue & MVIT_EPI_BIAS) ? bias : nullptr, residual, ldr, row_scale,
+                                           rows_per_scale, y, nullptr, ldy, M, N, K, st);
+    }
     static const bool use_dma = getenv("MVIT_GEMM_NO_DMA") == nullptr;
     static const bool use_big = getenv("MVIT_GEMM_NO_BIG") == nullptr;
     if (a_dtype == MVIT_BF16 && use_big && N % G_BN == 0 && G_KOK(K) && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31) &&
@@ -1227,6 +1212,8 @@ extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_PERS") == nullptr && getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
+    if (fused && use_pp(lda, M, N, K))
+        return mvit_internal_linear_pp(PP_GELU_PRE, a, lda, w, bias, nullptr, 0, nullptr, 0, y, pre, N, M, N, K, as_stream(stream));
     if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_pers<bf16_t, 2>(a, lda, w, bias, pre, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
     const int rc = mvit_linear_fwd(a, MVIT_BF16, lda, w, bias, nullptr, 0, nullptr, 0, pre, MVIT_BF16, N, M, N, K, MVIT_EPI_BIAS, act_dtype, stream);
@@ -1244,6 +1231,8 @@ extern "C" int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, 
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
+    if (fused && use_pp(lda, M, N, K))
+        return mvit_internal_linear_pp(PP_DG_PRE, a, lda, w, nullptr, pre, N, row_scale, rows_per_scale, y, nullptr, N, M, N, K, as_stream(stream));
     if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_big_t<bf16_t, false, false, 1>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
                                                             rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
@@ -1263,6 +1252,8 @@ extern "C" int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    if (use_pp(lda, M, N, K))
+        return mvit_internal_linear_pp(PP_GELU_DER, a, lda, w, bias, nullptr, 0, nullptr, 0, y, dact, N, M, N, K, as_stream(stream));
     return launch_linear_pers<bf16_t, 3>(a, lda, w, bias, dact, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
 }
 extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, const float* row_scale, int64_t rows_per_scale,
@@ -1271,6 +1262,8 @@ extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    if (use_pp(lda, M, N, K))
+        return mvit_internal_linear_pp(PP_DG_DER, a, lda, w, nullptr, dact, N, row_scale, rows_per_scale, y, nullptr, N, M, N, K, as_stream(stream));
     return launch_linear_big_t<bf16_t, false, false, 2>(a, lda, w, nullptr, reinterpret_cast<const float*>(dact), N, row_scale,
                                                         rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
 }

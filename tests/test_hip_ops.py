@@ -199,6 +199,52 @@ def test_linear_gelu_derivative_pair(hip_lib, N, K, K2):
                                               _hip.BF16, _st()) != 0     # N = 96: not a 128x192 shape
 
 
+@pytest.mark.parametrize("M,N,K", [(8192 + 40, 192, 128), (256 * 70 + 13, 576, 192), (256 * 33, 384, 1536), (8192 + 200, 1536, 384)])
+def test_linear_pingpong_all_epilogues(hip_lib, M, N, K):
+    """The 256 x 192 ping-pong kernel (linear_pp.hip; M >= 8192 routes to it): every epilogue it implements, ragged M, more tiles
+    than workgroups, against fp32 torch on the same 16-bit operands."""
+    a = _rnd(M, K, seed=61).to(torch.bfloat16).to(DEV)
+    w = _rnd(N, K, seed=62, scale=0.06).to(torch.bfloat16).to(DEV)
+    bias = _rnd(N, seed=63, scale=0.2).to(DEV)
+    res = _rnd(M, N, seed=64).to(DEV)
+    rps = 1000
+    sc = (torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(7)) * 2).to(DEV)
+    scr = sc.repeat_interleave(rps)[:M, None]
+    acc = a.float() @ w.float().t()
+
+    def lin(flags, out_dt, residual=None, scale=None, with_bias=True):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16 if out_dt == _hip.BF16 else torch.float32, device=DEV)
+        _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(a), _hip.BF16, K, _hip.ptr(w), _hip.ptr(bias) if with_bias else None, _hip.ptr(residual), N,
+                                           _hip.ptr(scale), rps, _hip.ptr(y), out_dt, N, M, N, K, flags, _hip.BF16, _st()))
+        return y
+    _close(lin(_hip.EPI_BIAS, _hip.BF16), (acc + bias).cpu(), 1e-2)
+    _close(lin(0, _hip.BF16, with_bias=False), acc.cpu(), 1e-2)
+    _close(lin(_hip.EPI_BIAS | _hip.EPI_GELU, _hip.BF16), F.gelu(acc + bias).cpu(), 1e-2)
+    _close(lin(_hip.EPI_BIAS, _hip.F32), (acc + bias).cpu(), 2e-3)
+    _close(lin(_hip.EPI_BIAS | _hip.EPI_RESIDUAL, _hip.F32, residual=res), (acc + bias + res).cpu(), 2e-3)
+    _close(lin(_hip.EPI_BIAS | _hip.EPI_RESIDUAL, _hip.F32, residual=res, scale=sc), ((acc + bias) * scr + res).cpu(), 2e-3)
+    # the MLP pairs of a training step
+    pre, y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_linear_gelu_fwd(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(pre), _hip.ptr(y), M, N, K, _hip.BF16, _st()))
+    assert torch.equal(pre, lin(_hip.EPI_BIAS, _hip.BF16))
+    _close(y, F.gelu(acc + bias).cpu(), 1e-2)
+    x = (acc + bias).clone().requires_grad_(True)
+    g = F.gelu(x)
+    g.sum().backward()
+    dact = torch.empty_like(pre)
+    _hip.check(hip_lib.mvit_linear_gelu_fwd_dsave(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(dact), _hip.ptr(y), M, N, K, _hip.BF16, _st()))
+    _close(y, g.detach().cpu(), 1e-2)
+    _close(dact, x.grad.cpu(), 1e-2)
+    aux = (_rnd(M, N, seed=65) * 1.5).to(torch.bfloat16).to(DEV)
+    xa = aux.float().requires_grad_(True)
+    F.gelu(xa).sum().backward()
+    out = torch.empty_like(pre)
+    _hip.check(hip_lib.mvit_linear_dgelu_fwd(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(sc), rps, _hip.ptr(aux), _hip.ptr(out), M, N, K, _hip.BF16, _st()))
+    _close(out, (xa.grad * acc * scr).cpu(), 1.5e-2)
+    _hip.check(hip_lib.mvit_linear_dact_fwd(_hip.ptr(a), K, _hip.ptr(w), None, 0, _hip.ptr(aux), _hip.ptr(out), M, N, K, _hip.BF16, _st()))
+    _close(out, (aux.float() * acc).cpu(), 1.5e-2)
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
