@@ -112,47 +112,39 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one v_rcp;
-// libm erff costs 30-60 VALU instructions per element and made the fc1 epilogue VALU-bound.
-__device__ __forceinline__ float gelu_grad_fast(float x) {      // d/dx GELU_erf, same erf approximation, exponential shared
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + erfv));
+// Fast erf-GELU for the 16-bit paths.  Phi(x) = 1 / (1 + 2^(x q(x^2))) with x q(x^2) = -log2(e) * p(x), p an odd minimax fit of
+// logit(Phi(x)) on |x| <= 5 (the logit of the normal CDF is odd, so one polynomial serves both tails and keeps the RELATIVE accuracy
+// of GELU(x) = x Phi(x) in the negative tail): 7 plain VALU + v_exp + v_rcp per element, against 14 + 2 for the Abramowitz-Stegun
+// 7.1.26 form used before (the fc1 epilogue was VALU-bound on it: 14 VALU instructions per MFMA, profiles/r2_pmc_gemm_fc1.txt).
+//   bf16 build: degree 7, |GELU error| <= 1.3e-3 |GELU| (2^-9.6) for |x| <= 5 and <= 8e-7 beyond, absolute <= 1.7e-4 -- below the
+//               2^-9 rounding of the 16-bit result; derivative within 2.7e-4;
+//   fp16 build: degree 13, relative <= 1.1e-4, absolute <= 1.2e-5 (the result keeps 11 bits), derivative within 2.3e-5.
+// Coefficients and the error scan: tools/fit_gelu.py.  p is increasing on the whole real line, so large |x| saturate to 0 / x.
+#ifdef MVIT_HALF_IS_FP16
+#define MVIT_GELU_NK 7
+__device__ static const float k_gelu[MVIT_GELU_NK] = {-2.301758256e+00f, -1.055243742e-01f, 3.938158157e-04f, 1.041289184e-04f, -6.513817968e-06f, 1.755232626e-07f, -1.842319936e-09f};
+#else
+#define MVIT_GELU_NK 4
+__device__ static const float k_gelu[MVIT_GELU_NK] = {-2.297646723e+00f, -1.093967574e-01f, 1.423557742e-03f, -1.303203199e-05f};
+#endif
+__device__ __forceinline__ float gelu_phi_fast(float x, float x2) {        // Phi(x); x2 = x * x
+    float q = k_gelu[MVIT_GELU_NK - 1];
+#pragma unroll
+    for (int i = MVIT_GELU_NK - 2; i >= 0; --i) q = fmaf(q, x2, k_gelu[i]);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q * x));
 }
-__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gval, float& gder) {     // GELU_erf(x) and its derivative, one exp + one rcp
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    const float cdf = 0.5f * (1.0f + erfv);
+__device__ __forceinline__ float gelu_fast(float x) { return x * gelu_phi_fast(x, x * x); }
+__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gval, float& gder) {     // GELU_erf(x) and its derivative Phi(x) + x phi(x)
+    const float x2 = x * x, cdf = gelu_phi_fast(x, x2);
+    const float e = __builtin_amdgcn_exp2f(x2 * -0.72134752044448170368f);          // exp(-x^2 / 2)
     gval = x * cdf;
     gder = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erfv);
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float gv, gd;
+    gelu_and_grad_fast(x, gv, gd);
+    return gd;
 }
-
 // D = A(32x16) * B(16x32) + C on 16-bit operands held as raw bits (bf16x8 = 8 shorts); fp32 accumulate
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef MVIT_HALF_IS_FP16

@@ -83,18 +83,17 @@ __device__ __forceinline__ void pp_dma(const char* base, uint32_t off, uint32_t 
 #define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #if PP_ABL & 8
-__device__ float g_pp_stamps[256 * 8 * 8 + 256 * 4 + 256 * 8 * 4];
-extern "C" int mvit_debug_pp_stamps(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(float) * (256 * 8 * 8 + 256 * 4 + 256 * 8 * 4)) == hipSuccess ? 0 : -3; }
-#define PP_STAMP(v) v = __builtin_readcyclecounter()
-#else
-#define PP_STAMP(v)
+__device__ float g_pp_stamps[256 * 4];
+extern "C" int mvit_debug_pp_stamps(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(float) * 256 * 4) == hipSuccess ? 0 : -3; }
 #endif
+
 struct PPCur {          // DMA cursor: source of one K-tile
     const char* ap;     // a + m0 * lda + k   (wave-uniform)
     const char* wp;     // w + n0 * K + k
-    uint32_t to[8];     // group 1: per-lane byte offsets of this wave's token pieces [half * 4 + i] (rows past M re-read row M - 1)
     int t, kt;
+    int rmax;           // last existing row of the tile's 256 (255 unless the tile hangs over M)
 };
 
 template <int EPI, typename TO>
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void linear_pp_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int grp = wave >> 2, wg = wave & 3, wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2, wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
 
     const int ntn = N / PP_BN;
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void linear_pp_kernel(
     const int t_first = xcd * q + (blockIdx.x >> 3);
     if (t_first >= t_end) return;
     const int nk = K / PP_BK;
-    const int g_total = ((t_end - t_first + per - 1) / per) * nk;
+    const int my_tiles = (t_end - t_first + per - 1) / per;
 
     float* sbias = reinterpret_cast<float*>(smem + PP_TILES_BYTES);
     for (int i = tid; i < N; i += 512) sbias[i] = bias ? bias[i] : 0.f;
@@ -130,16 +129,24 @@ __global__ __launch_bounds__(512, 2) void linear_pp_kernel(
         ta[ks] = lds0 + grp * PP_T_HALF + (64 * (wm & 1) + l15) * 128 + fo;
         wa[ks] = lds0 + PP_W_OFF + (96 * wn + l15) * 128 + fo;
     }
-    // DMA pieces (1 KiB = 8 rows x 128 B, lane -> row lane / 8, position lane % 8).  Group 0 moves the weight tiles (wave wg:
-    // rows 48 wg + 8 i, i < 6), group 1 the token tiles (wave wg: rows 32 wg + 8 i, i < 4, of T0 and of T1).
-    uint32_t wo[6];
+    // DMA pieces of this wave (1 KiB = 8 rows x 128 B, lane -> row lane / 8, position lane % 8): T0 / T1 / Wa rows 16 wave + 8 i,
+    // Wb row 128 + 8 wave.  Per-lane byte offsets; the token offsets assume a full tile (the ragged last row panel recomputes them)
+    const int prow = 16 * wave + (lane >> 3);
+    uint32_t wo[2], wob, to[2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int row = 48 * wg + 8 * i + (lane >> 3);
-        wo[i] = (uint32_t)(row * K + 8 * ((lane & 7) ^ ((row >> 1) & 7))) * 2u;
+    for (int i = 0; i < 2; ++i) {
+        const int row = prow + 8 * i, ch = (lane & 7) ^ ((row >> 1) & 7);
+        wo[i] = (uint32_t)(row * K + 8 * ch) * 2u;
+        to[i] = (uint32_t)(row * (int)lda + 8 * ch) * 2u;
     }
-    const uint32_t d_w = lds0 + PP_W_OFF + 1024 * (6 * wg);       // + 1024 i + buffer
-    const uint32_t d_t = lds0 + 1024 * (4 * wg);                  // + half * PP_T_HALF + 1024 i + buffer
+    {
+        const int rowb = 128 + 8 * wave + (lane >> 3);
+        wob = (uint32_t)(rowb * K + 8 * ((lane & 7) ^ ((rowb >> 1) & 7))) * 2u;
+    }
+    const uint32_t d_t = lds0 + 1024 * (2 * wave);                  // + half * PP_T_HALF + 1024 i + buffer
+    const uint32_t d_wa = lds0 + PP_W_OFF + 1024 * (2 * wave);      // + 1024 i + buffer
+    const uint32_t d_wb = lds0 + PP_WB_OFF + 1024 * wave;
+    const int64_t half_bytes = 128 * lda * 2;                       // T1 rows = T0 rows + 128
 
     auto setup = [&](PPCur& c, int tile) {
         const int64_t m0 = (int64_t)(tile / ntn) * PP_BM;
@@ -147,46 +154,46 @@ __global__ __launch_bounds__(512, 2) void linear_pp_kernel(
         c.wp = reinterpret_cast<const char*>(w + (int64_t)(tile % ntn) * PP_BN * K);
         c.t = tile;
         c.kt = 0;
-        if (grp) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = 128 * h + 32 * wg + 8 * i + (lane >> 3);
-                    const int ch = (lane & 7) ^ ((row >> 1) & 7);
-                    const int rr = m0 + row < M ? row : (int)(M - 1 - m0);
-                    c.to[4 * h + i] = (uint32_t)(rr * (int)lda + 8 * ch) * 2u;
-                }
-        }
+        const int64_t left = M - 1 - m0;
+        c.rmax = left > 255 ? 255 : (int)left;
     };
     auto advance = [&](PPCur& c) {
         if (c.kt + 1 < nk) { ++c.kt; c.ap += 2 * PP_BK; c.wp += 2 * PP_BK; }
         else if (c.t + per < t_end) setup(c, c.t + per);
         // else: past the last K-tile of this workgroup -- the cursor stays (harmless re-reads into consumed buffers)
     };
-    auto dma_t = [&](const PPCur& c, int half, uint32_t bo) {      // group 1: 4 pieces of T0 / T1
+    auto dma_t = [&](const PPCur& c, int half, uint32_t bo) {
+        if (c.rmax >= 255) {
+            const char* base = c.ap + half * half_bytes;
+            pp_dma(base, to[0], d_t + half * PP_T_HALF + bo);
+            pp_dma(base, to[1], d_t + half * PP_T_HALF + bo + 1024);
+        } else {        // the ragged last row panel: rows past M re-read row M - 1 (never stored)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pp_dma(c.ap, c.to[4 * half + i], d_t + half * PP_T_HALF + bo + 1024 * i);
+            for (int i = 0; i < 2; ++i) {
+                const int row = 128 * half + prow + 8 * i, rr = row < c.rmax ? row : c.rmax;
+                pp_dma(c.ap, (uint32_t)(rr * (int)lda + 8 * ((lane & 7) ^ ((row >> 1) & 7))) * 2u, d_t + half * PP_T_HALF + bo + 1024 * i);
+            }
+        }
     };
-    auto dma_w = [&](const PPCur& c, uint32_t bo) {                // group 0: 6 pieces of W
-#pragma unroll
-        for (int i = 0; i < 6; ++i) pp_dma(c.wp, wo[i], d_w + bo + 1024 * i);
+    auto dma_wa = [&](const PPCur& c, uint32_t bo) {
+        pp_dma(c.wp, wo[0], d_wa + bo);
+        pp_dma(c.wp, wo[1], d_wa + bo + 1024);
     };
+    auto dma_wb = [&](const PPCur& c, uint32_t bo) { pp_dma(c.wp, wob, d_wb + bo); };
 
-    // prologue: K-tile 0 (group 0: W(0); group 1: T0(0), T1(0)) and, group 1, T0(1)
     PPCur c1, c2;
     {
         PPCur c0;
         setup(c0, t_first);
         c1 = c0; advance(c1);
         c2 = c1; advance(c2);
-        if (!grp) { dma_w(c0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        else { dma_t(c0, 0, 0); dma_t(c0, 1, 0); dma_t(c1, 0, PP_BUF); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        dma_wa(c0, 0); dma_t(c0, 0, 0); dma_t(c0, 1, 0); dma_wb(c0, 0);
+        dma_wa(c1, PP_BUF); dma_t(c1, 0, PP_BUF);
     }
 
     // acc[mt][nt]: token 64 wm + 16 mt + l15 ; columns 96 wn + 16 nt + 4 lg + (0..3)
     f32x4 acc[4][6];
-    int t_cur = t_first, kt_cur = 0;
+    int t_cur = t_first;
     auto init_acc = [&](int tile) {
         const int n0 = (tile % ntn) * PP_BN;
 #pragma unroll
@@ -198,205 +205,207 @@ __global__ __launch_bounds__(512, 2) void linear_pp_kernel(
     };
     init_acc(t_cur);
 
-    constexpr int NST = (EPI == PP_B16 || EPI == PP_GELU16 || EPI == PP_DG_PRE || EPI == PP_DG_DER) ? 12 : 24;   // vector stores per wave and full tile
-    bool trail = false;
-    bf16x8 tf[4][2], wf[6][2];            // [16-row block][k-step]
-    PP_BARRIER();                                         // K-tile 0 has landed for everyone
+    // per-lane byte offsets of a wave's output rows: a wave-uniform base (SALU) + ONE constant lane offset
+    const uint32_t lane_o16 = (uint32_t)(l15 * (int)ldy + 16 * (lg & 1) + 8 * (lg >> 1)) * 2u;     // 16-bit pieces: block nt + (lg & 1), columns 8 (lg >> 1)..
+    auto st16 = [&](const char* base, int mt, int np, int lim, u32x4 v) {     // base / mt / np / lim wave-uniform
+        char* p_ = const_cast<char*>(base) + ((int64_t)(16 * mt) * ldy + 32 * np) * 2;
+        if (l15 + 16 * mt < lim) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_o16), "v"(v), "s"(p_) : "memory");   // the nop: hipcc may overwrite the data registers right behind an asm store
+    };
+
+    bf16x8 tf[2][2][2], wf[2][3][2];      // [set][block][k-step]
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 has landed (Wa(1), T0(1) may still fly)
+    PP_BARRIER();
+    tf[0][0][0] = pp_rd<0>(ta[0]); tf[0][0][1] = pp_rd<0>(ta[1]);
+    tf[0][1][0] = pp_rd<2048>(ta[0]); tf[0][1][1] = pp_rd<2048>(ta[1]);
     if (grp) PP_BARRIER();                                // the stagger: group 1 runs one slot behind group 0
     PP_SB();
-
 #if PP_ABL & 8
-    uint64_t tA, tB, tC, tD, tE, tF, tG, tH, tI = 0, sm[7] = {0, 0, 0, 0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
-    bool st_epi = false, st_first = false;
     const uint64_t loop_c0 = __builtin_readcyclecounter(), loop_r0 = __builtin_readsteadycounter();
-#define PP_T(v) v = __builtin_readcyclecounter()
-#else
-#define PP_T(v)
+    uint64_t s_epi = 0;
 #endif
-#define PP_PRIO(x) if (!(PP_ABL & 16)) asm volatile("s_setprio " #x)
 
-    // Slot s of the workgroup: group 0 is in L(G) for s = 2 G and in M(G) for s = 2 G + 1, group 1 one slot later.
-    //   L(G): reads the 20 fragments of K-tile G from buffer b = G & 1; group 0 then issues W(G+1) -> b^1 (its last readers, group
-    //         1 in slot 2 G - 1, retired their reads before that slot's barrier), group 1 issues T1(G+1) -> b^1 and T0(G+2) -> b
-    //         (T0[b] was last read by group 0 in slot 2 G, one slot earlier); lgkmcnt(0) BEFORE the closing barrier.
-    //   M(G): 48 MFMAs; before the closing barrier group 0 waits vmcnt(0) (W(G+1) landed: read from slot 2 G + 2 on) and group 1
-    //         vmcnt(4) (T1(G+1) landed: read in slot 2 G + 3; T0(G+2) keeps flying until the vmcnt(8) that ends L(G+1), one
-    //         barrier before group 0 reads it in slot 2 G + 4).
-    for (int g = 0; g < g_total; ++g) {
+#define PP_PRIO(x) if (!(PP_ABL & 16)) asm volatile("s_setprio " #x)
+#define PP_MM(MSET, NSET, TS, WS) \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int nt_ = 0; nt_ < 3; ++nt_) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) \
+        acc[2 * MSET + mt][3 * NSET + nt_] = pp_mfma(wf[WS][nt_][ks], tf[TS][mt][ks], acc[2 * MSET + mt][3 * NSET + nt_]);
+#define PP_WAIT_W(S) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[S][0][0]), "+v"(wf[S][0][1]), "+v"(wf[S][1][0]), "+v"(wf[S][1][1]), "+v"(wf[S][2][0]), "+v"(wf[S][2][1]))
+#define PP_WAIT_T(S) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tf[S][0][0]), "+v"(tf[S][0][1]), "+v"(tf[S][1][0]), "+v"(tf[S][1][1]))
+#define PP_MSEG(BODY) { PP_PRIO(1); PP_SB(); BODY PP_SB(); PP_PRIO(0); PP_BARRIER(); PP_SB(); }
+
+    int g = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      for (int kt_cur = 0; kt_cur < nk; ++kt_cur, ++g) {
         const uint32_t bo = (g & 1) ? PP_BUF : 0, nbo = PP_BUF - bo;
+        // ---- L0: w0(G) ; DMA T1(G+1) ----------------------------------------------------------------------------
         {
-            PP_T(tA);
-#if PP_ABL & 8
-            if (g) { if (st_epi) sx[1] += tA - tI; else sx[0] += tA - tI; }
-            st_first = st_epi; st_epi = false;
-#endif
-            const uint32_t t0 = ta[0] + bo, t1 = ta[1] + bo, w0 = wa[0] + bo, w1 = wa[1] + bo;
-            tf[0][0] = pp_rd<0>(t0); tf[0][1] = pp_rd<0>(t1);
-            wf[0][0] = pp_rd<0>(w0); wf[0][1] = pp_rd<0>(w1);
-            wf[1][0] = pp_rd<2048>(w0); wf[1][1] = pp_rd<2048>(w1);
-            wf[2][0] = pp_rd<4096>(w0); wf[2][1] = pp_rd<4096>(w1);
-            tf[1][0] = pp_rd<2048>(t0); tf[1][1] = pp_rd<2048>(t1);
-            wf[3][0] = pp_rd<6144>(w0); wf[3][1] = pp_rd<6144>(w1);
-            wf[4][0] = pp_rd<8192>(w0); wf[4][1] = pp_rd<8192>(w1);
-            wf[5][0] = pp_rd<10240>(w0); wf[5][1] = pp_rd<10240>(w1);
-            tf[2][0] = pp_rd<4096>(t0); tf[2][1] = pp_rd<4096>(t1);
-            tf[3][0] = pp_rd<6144>(t0); tf[3][1] = pp_rd<6144>(t1);
-            PP_T(tB);
-            if (!grp) dma_w(c1, nbo);
-            else { dma_t(c1, 1, nbo); dma_t(c2, 0, bo); }
-            PP_T(tC);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(tf[0][0]), "+v"(tf[0][1]), "+v"(tf[1][0]), "+v"(tf[1][1]), "+v"(tf[2][0]), "+v"(tf[2][1]), "+v"(tf[3][0]), "+v"(tf[3][1]));
-            asm volatile("" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]));
-            asm volatile("" : "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[4][0]), "+v"(wf[4][1]), "+v"(wf[5][0]), "+v"(wf[5][1]));
-            PP_T(tD);
-            if (grp) {      // T0(G+1) has landed; the NST stores of a full tile's epilogue just before this segment may still fly
-                if (trail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                trail = false;
-            }
-            PP_T(tE);
-            PP_SB(); PP_BARRIER(); PP_SB();
-            PP_T(tF);
+            const uint32_t w0 = wa[0] + bo, w1 = wa[1] + bo;
+            wf[0][0][0] = pp_rd<0>(w0); wf[0][0][1] = pp_rd<0>(w1);
+            wf[0][1][0] = pp_rd<2048>(w0); wf[0][1][1] = pp_rd<2048>(w1);
+            wf[0][2][0] = pp_rd<4096>(w0); wf[0][2][1] = pp_rd<4096>(w1);
+            dma_t(c1, 1, nbo);
+            PP_SB(); PP_BARRIER();
+            PP_WAIT_W(0);
+            PP_SB();
         }
-        PP_PRIO(1); PP_SB();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt_ = 0; nt_ < 6; ++nt_)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt_] = pp_mfma(wf[nt_][ks], tf[mt][ks], acc[mt][nt_]);
-        PP_SB(); PP_PRIO(0);
-        PP_T(tG);
-        if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        PP_T(tH);
-        PP_BARRIER();
-#if PP_ABL & 8
-        { tI = __builtin_readcyclecounter();
-          if (st_first) { sx[2] += tE - tD; sx[3] += tH - tG; }
-          sm[0] += tB - tA; sm[1] += tC - tB; sm[2] += tD - tC; sm[3] += tE - tD; sm[4] += tF - tE; sm[5] += tG - tF; sm[6] += (tH - tG) + ((tI - tH) << 20); }
-#endif
-        PP_SB();
+        PP_MSEG(PP_MM(0, 0, 0, 0))
+        // ---- L1: w1(G) ; DMA Wb(G+1) ; reads retired BEFORE the barrier (Wa(G+2) is issued in the next slot) -------
+        {
+            const uint32_t w0 = wa[0] + bo, w1 = wa[1] + bo;
+            wf[1][0][0] = pp_rd<6144>(w0); wf[1][0][1] = pp_rd<6144>(w1);
+            wf[1][1][0] = pp_rd<8192>(w0); wf[1][1][1] = pp_rd<8192>(w1);
+            wf[1][2][0] = pp_rd<10240>(w0); wf[1][2][1] = pp_rd<10240>(w1);
+            dma_wb(c1, nbo);
+            PP_WAIT_W(1);
+            PP_SB(); PP_BARRIER(); PP_SB();
+        }
+        PP_MSEG(PP_MM(0, 1, 0, 1))
+        // ---- L2: t1(G) ; DMA Wa(G+2) ; T0(G+1), T1(G+1) landed --------------------------------------------------------
+        {
+            const uint32_t t0 = ta[0] + bo, t1 = ta[1] + bo;
+            tf[1][0][0] = pp_rd<4096>(t0); tf[1][0][1] = pp_rd<4096>(t1);
+            tf[1][1][0] = pp_rd<6144>(t0); tf[1][1][1] = pp_rd<6144>(t1);
+            dma_wa(c2, bo);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            PP_SB(); PP_BARRIER();
+            PP_WAIT_T(1);
+            PP_SB();
+        }
+        PP_MSEG(PP_MM(1, 1, 1, 1))
+        // ---- L3: t0(G+1) ; DMA T0(G+2) ; W(G+1) landed -------------------------------------------------------------------
+        {
+            const uint32_t t0 = ta[0] + nbo, t1 = ta[1] + nbo;
+            tf[0][0][0] = pp_rd<0>(t0); tf[0][0][1] = pp_rd<0>(t1);
+            tf[0][1][0] = pp_rd<2048>(t0); tf[0][1][1] = pp_rd<2048>(t1);
+            dma_t(c2, 0, bo);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            PP_SB(); PP_BARRIER();
+            PP_WAIT_T(0);
+            PP_SB();
+        }
+        PP_MSEG(PP_MM(1, 0, 1, 0))
         c1 = c2;
         advance(c2);
-
-        if (++kt_cur < nk) continue;
+      }
         // ================= epilogue of tile t_cur (no barrier inside: both groups keep their barrier count) =================
+#if PP_ABL & 8
+        const uint64_t e0 = __builtin_readcyclecounter();
+#endif
         {
-            const int64_t m0 = (int64_t)(t_cur / ntn) * PP_BM + 64 * wm + l15;     // + 16 mt
-            const int nb = (t_cur % ntn) * PP_BN + 96 * wn;                        // + 16 nt + 4 lg
-            const bool full_m = (int64_t)(t_cur / ntn) * PP_BM + PP_BM <= M;
-            auto emit = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
+            const int64_t mw = (int64_t)(t_cur / ntn) * PP_BM + 64 * wm;          // first row of this wave (wave-uniform); lane row = mw + 16 mt + l15
+            const int nb = (t_cur % ntn) * PP_BN + 96 * wn;                        // first column of this wave
+            const int64_t left = M - mw;
+            const int lim = left > 64 ? 64 : (left < 0 ? 0 : (int)left);           // existing rows below mw
+            const char* yb = reinterpret_cast<const char*>(y) + (mw * ldy + nb) * (int64_t)sizeof(TO);
+            [[maybe_unused]] const char* y2b = reinterpret_cast<const char*>(y2) + (mw * ldy + nb) * (int64_t)sizeof(TO);
+            if constexpr (EPI == PP_F32 || EPI == PP_F32_RES || EPI == PP_F32_RES_SC) {
+                // fp32 rows: every residual load of the wave tile is requested before the first add (one round trip, not four)
+                [[maybe_unused]] float4 rr[4][6];
+                int64_t rowo[4];
+                bool okv[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int64_t m = m0 + 16 * mt;
-                    const bool ok = FULL || m < M;
-                    const int64_t mc = ok ? m : M - 1;
-                    [[maybe_unused]] float sc = 1.f;
-                    if constexpr (EPI == PP_F32_RES_SC) sc = row_scale[(uint32_t)mc / (uint32_t)rps];
-                    if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) sc = row_scale ? row_scale[(uint32_t)mc / (uint32_t)rps] : 1.f;
-                    if constexpr (EPI == PP_F32 || EPI == PP_F32_RES || EPI == PP_F32_RES_SC) {
-                        float* yr = reinterpret_cast<float*>(y) + mc * ldy + nb + 4 * lg;
-                        [[maybe_unused]] float4 rr[6];
-                        if constexpr (EPI != PP_F32) {
-                            const float* rp = reinterpret_cast<const float*>(aux) + mc * ldaux + nb + 4 * lg;
+                    okv[mt] = l15 + 16 * mt < lim;
+                    rowo[mt] = mw + (okv[mt] ? l15 + 16 * mt : (int)(M - 1 - mw));   // masked lanes load an existing row
+                }
+                if constexpr (EPI != PP_F32) {
 #pragma unroll
-                            for (int nt_ = 0; nt_ < 6; ++nt_) rr[nt_] = load4(rp + 16 * nt_);
-                        }
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float* rp = reinterpret_cast<const float*>(aux) + rowo[mt] * ldaux + nb + 4 * lg;
 #pragma unroll
-                        for (int nt_ = 0; nt_ < 6; ++nt_) {
-                            float4 v = make_float4(acc[mt][nt_][0], acc[mt][nt_][1], acc[mt][nt_][2], acc[mt][nt_][3]);
-                            if constexpr (EPI == PP_F32_RES_SC) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-                            if constexpr (EPI != PP_F32) { v.x += rr[nt_].x; v.y += rr[nt_].y; v.z += rr[nt_].z; v.w += rr[nt_].w; }
-                            if (ok) *reinterpret_cast<float4*>(yr + 16 * nt_) = v;
-                        }
-                    } else {
-                        // 16-bit outputs: accumulators nt, nt+1 exchanged by v_permlane16_swap -> every lane holds 8 consecutive
-                        // columns: lane group lg -> block nt + (lg & 1), columns 8 (lg >> 1) .. +7
-                        const int64_t pofs = mc * ldy + nb + 16 * (lg & 1) + 8 * (lg >> 1);     // + 16 nt (nt even)
-                        [[maybe_unused]] uint4 ax[3];
-                        if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) {
-                            const bf16_t* ap_ = reinterpret_cast<const bf16_t*>(aux) + mc * ldaux + nb + 16 * (lg & 1) + 8 * (lg >> 1);
-#pragma unroll
-                            for (int np = 0; np < 3; ++np) ax[np] = *reinterpret_cast<const uint4*>(ap_ + 32 * np);
-                        }
-#pragma unroll
-                        for (int np = 0; np < 3; ++np) {
-                            f32x4 X = acc[mt][2 * np], Y = acc[mt][2 * np + 1];
-                            auto put = [&](TO* dst, f32x4 A_, f32x4 B_) {
-                                const uint32_t x0 = pack_bf16x2(A_[0], A_[1]), x1 = pack_bf16x2(A_[2], A_[3]);
-                                const uint32_t y0 = pack_bf16x2(B_[0], B_[1]), y1 = pack_bf16x2(B_[2], B_[3]);
-                                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                                const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                                if (ok) *reinterpret_cast<uint4*>(dst + pofs + 32 * np) = o;
-                            };
-                            if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) {
-                                // the aux piece is in the stored (exchanged) layout: the same swap hands every lane the values of its own columns
-                                const auto u0 = __builtin_amdgcn_permlane16_swap(ax[np].x, ax[np].z, false, false);
-                                const auto u1 = __builtin_amdgcn_permlane16_swap(ax[np].y, ax[np].w, false, false);
-                                float fx[4] = {lo16_to_f32(u0[0]), hi16_to_f32(u0[0]), lo16_to_f32(u1[0]), hi16_to_f32(u1[0])};
-                                float fy[4] = {lo16_to_f32(u0[1]), hi16_to_f32(u0[1]), lo16_to_f32(u1[1]), hi16_to_f32(u1[1])};
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    if constexpr (EPI == PP_DG_PRE) { fx[j] = gelu_grad_fast(fx[j]); fy[j] = gelu_grad_fast(fy[j]); }
-                                    X[j] *= sc * fx[j];
-                                    Y[j] *= sc * fy[j];
-                                }
-                            }
-                            if constexpr (EPI == PP_GELU_PRE) put(y2, X, Y);
-                            if constexpr (EPI == PP_GELU_DER) {
-                                f32x4 dX, dY;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    float gv, gd;
-                                    gelu_and_grad_fast(X[j], gv, gd); X[j] = gv; dX[j] = gd;
-                                    gelu_and_grad_fast(Y[j], gv, gd); Y[j] = gv; dY[j] = gd;
-                                }
-                                put(y2, dX, dY);
-                            }
-                            if constexpr (EPI == PP_GELU16 || EPI == PP_GELU_PRE) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { X[j] = gelu_fast(X[j]); Y[j] = gelu_fast(Y[j]); }
-                            }
-                            put(y, X, Y);
-                        }
+                        for (int nt_ = 0; nt_ < 6; ++nt_) rr[mt][nt_] = load4(rp + 16 * nt_);
                     }
                 }
-            };
-            if (full_m) emit(std::true_type{}); else emit(std::false_type{});
-            trail = full_m;
-#if PP_ABL & 8
-            st_epi = true;
-#endif
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    [[maybe_unused]] float sc = 1.f;
+                    if constexpr (EPI == PP_F32_RES_SC) sc = row_scale[(uint32_t)rowo[mt] / (uint32_t)rps];
+                    float* yr = reinterpret_cast<float*>(y) + rowo[mt] * ldy + nb + 4 * lg;
+#pragma unroll
+                    for (int nt_ = 0; nt_ < 6; ++nt_) {
+                        float4 v = make_float4(acc[mt][nt_][0], acc[mt][nt_][1], acc[mt][nt_][2], acc[mt][nt_][3]);
+                        if constexpr (EPI == PP_F32_RES_SC) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                        if constexpr (EPI != PP_F32) { v.x += rr[mt][nt_].x; v.y += rr[mt][nt_].y; v.z += rr[mt][nt_].z; v.w += rr[mt][nt_].w; }
+                        if (okv[mt]) *reinterpret_cast<float4*>(yr + 16 * nt_) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bool ok = l15 + 16 * mt < lim;
+                    const int64_t rowl = mw + (ok ? l15 + 16 * mt : (int)(M - 1 - mw));       // an existing row for the loads of masked lanes
+                    [[maybe_unused]] float sc = 1.f;
+                    if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) sc = row_scale ? row_scale[(uint32_t)rowl / (uint32_t)rps] : 1.f;
+                    // 16-bit outputs: accumulators nt, nt+1 exchanged by v_permlane16_swap -> every lane holds 8 consecutive
+                    // columns: lane group lg -> block nt + (lg & 1), columns 8 (lg >> 1) .. +7
+                    [[maybe_unused]] uint4 ax[3];
+                    if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) {
+                        const bf16_t* ap_ = reinterpret_cast<const bf16_t*>(aux) + rowl * ldaux + nb + 16 * (lg & 1) + 8 * (lg >> 1);
+#pragma unroll
+                        for (int np = 0; np < 3; ++np) ax[np] = *reinterpret_cast<const uint4*>(ap_ + 32 * np);
+                    }
+#pragma unroll
+                    for (int np = 0; np < 3; ++np) {
+                        f32x4 X = acc[mt][2 * np], Y = acc[mt][2 * np + 1];
+                        auto pair16 = [&](f32x4 A_, f32x4 B_) {
+                            const uint32_t x0 = pack_bf16x2(A_[0], A_[1]), x1 = pack_bf16x2(A_[2], A_[3]);
+                            const uint32_t y0 = pack_bf16x2(B_[0], B_[1]), y1 = pack_bf16x2(B_[2], B_[3]);
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                            return u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        };
+                        if constexpr (EPI == PP_DG_PRE || EPI == PP_DG_DER) {
+                            // the aux piece is in the stored (exchanged) layout: the same swap hands every lane the values of its own columns
+                            const auto u0 = __builtin_amdgcn_permlane16_swap(ax[np].x, ax[np].z, false, false);
+                            const auto u1 = __builtin_amdgcn_permlane16_swap(ax[np].y, ax[np].w, false, false);
+                            float fx[4] = {lo16_to_f32(u0[0]), hi16_to_f32(u0[0]), lo16_to_f32(u1[0]), hi16_to_f32(u1[0])};
+                            float fy[4] = {lo16_to_f32(u0[1]), hi16_to_f32(u0[1]), lo16_to_f32(u1[1]), hi16_to_f32(u1[1])};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr (EPI == PP_DG_PRE) { fx[j] = gelu_grad_fast(fx[j]); fy[j] = gelu_grad_fast(fy[j]); }
+                                X[j] *= sc * fx[j];
+                                Y[j] *= sc * fy[j];
+                            }
+                        }
+                        if constexpr (EPI == PP_GELU_PRE) st16(y2b, mt, np, lim, pair16(X, Y));
+                        if constexpr (EPI == PP_GELU_DER) {
+                            f32x4 dX, dY;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float gv, gd;
+                                gelu_and_grad_fast(X[j], gv, gd); X[j] = gv; dX[j] = gd;
+                                gelu_and_grad_fast(Y[j], gv, gd); Y[j] = gv; dY[j] = gd;
+                            }
+                            st16(y2b, mt, np, lim, pair16(dX, dY));
+                        }
+                        if constexpr (EPI == PP_GELU16 || EPI == PP_GELU_PRE) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { X[j] = gelu_fast(X[j]); Y[j] = gelu_fast(Y[j]); }
+                        }
+                        st16(yb, mt, np, lim, pair16(X, Y));
+                    }
+                }
+            }
         }
-        kt_cur = 0;
         t_cur += per;
-        if (g + 1 < g_total) init_acc(t_cur);
+        if (ti + 1 < my_tiles) init_acc(t_cur);
         PP_SB();
+#if PP_ABL & 8
+        s_epi += __builtin_readcyclecounter() - e0;
+#endif
     }
 #if PP_ABL & 8
-    if (lane == 0) {
-        float* o = g_pp_stamps + (blockIdx.x * 8 + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) o[i] = (float)sm[i] / g_total;
-        o[6] = (float)(sm[6] & 0xfffff) / g_total;
-        o[7] = (float)(sm[6] >> 20) / g_total;
-        {
-            float* x = g_pp_stamps + 256 * 8 * 8 + 256 * 4 + (blockIdx.x * 8 + wave) * 4;
-            const float ntile = (float)(g_total / nk);
-            x[0] = (float)sx[0] / (g_total - ntile); x[1] = ntile > 1 ? (float)sx[1] / (ntile - 1) : 0.f; x[2] = ntile > 1 ? (float)sx[2] / (ntile - 1) : 0.f; x[3] = ntile > 1 ? (float)sx[3] / (ntile - 1) : 0.f;
-        }
-        if (wave == 0) {    // whole-loop cycles and 100 MHz ticks -> the clock the loop ran at; K-tiles of this workgroup
-            float* e = g_pp_stamps + 256 * 8 * 8 + blockIdx.x * 4;
-            e[0] = (float)(__builtin_readcyclecounter() - loop_c0); e[1] = (float)(__builtin_readsteadycounter() - loop_r0); e[2] = (float)g_total; e[3] = (float)nk;
-        }
+    if (lane == 0 && wave == 0) {    // whole-loop cycles and 100 MHz ticks -> the clock the loop ran at; K-tiles; epilogue cycles per tile
+        float* e = g_pp_stamps + blockIdx.x * 4;
+        e[0] = (float)(__builtin_readcyclecounter() - loop_c0); e[1] = (float)(__builtin_readsteadycounter() - loop_r0); e[2] = (float)(my_tiles * nk);
+        e[3] = (float)s_epi / my_tiles;
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
     if (!grp) PP_BARRIER();                               // group 0 is one barrier short of group 1
+#undef PP_MM
+#undef PP_WAIT_W
+#undef PP_WAIT_T
+#undef PP_MSEG
 }
 
 template <int EPI, typename TO>

@@ -55,29 +55,17 @@ def main():
         fl = 2.0 * M * N * K
         by = M * K * 2 + N * K * 2 + M * N * (4 if out_f32 else 2) + (M * N * 4 if res is not None else 0)
         print("gemm M=%d N=%d K=%d epi=%s: %.1f us  %.1f TFLOP/s  %.2f TB/s" % (M, N, K, epi, ms * 1e3, fl / ms / 1e9, by / ms / 1e9))
-        if os.environ.get("PP_STAMPS"):      # library built with -DPP_ABL=8: per-wave cycle sums of the ping-pong kernel's segments
+        if os.environ.get("PP_STAMPS"):      # library built with -DPP_ABL=8 (tools/build_pp_abl.sh 8): loop cycles / clock / epilogue cycles of the ping-pong kernel
             import ctypes
-            buf = (ctypes.c_float * (256 * 8 * 8 + 256 * 4 + 256 * 8 * 4))()
+            buf = (ctypes.c_float * (256 * 4))()
             L.mvit_debug_pp_stamps.restype = ctypes.c_int
             torch.cuda.synchronize()
             assert L.mvit_debug_pp_stamps(buf) == 0
-            allv = torch.tensor(list(buf))
-            e = allv[256 * 8 * 8:256 * 8 * 8 + 256 * 4].view(256, 4)
-            xx = allv[256 * 8 * 8 + 256 * 4:].view(256, 8, 4)
-            xx = xx[e[:, 2] == e[:, 2].max()]
+            e = torch.tensor(list(buf)).view(256, 4)
             e = e[e[:, 2] > 0]
             big = e[e[:, 2] == e[:, 2].max()]
-            print("  loop: %.0f cycles, %.2f us, clock %.2f GHz, %d K-tiles (longest workgroups: %d of %d); cycles per K-tile incl. epilogues %.0f" % (
-                big[:, 0].mean(), big[:, 1].mean() / 100, big[:, 0].mean() / big[:, 1].mean() / 10, int(big[0, 2]), len(big), len(e), (big[:, 0] / big[:, 2]).mean()))
-            t = allv[:256 * 8 * 8].view(256, 8, 8)
-            for grp in (0, 1):
-                g = xx[:, 4 * grp:4 * grp + 4].mean(dim=(0, 1))
-                print("  group %d (longest workgroups): loop tail without epilogue %.0f, with epilogue %.0f; first K-tile after an epilogue: vm-wait in L %.0f, in M %.0f" % (grp, g[0], g[1], g[2], g[3]))
-            t = t[t[:, 0, 5] > 0]
-            names = "read-issue dma-issue lgkm-wait vm-wait barrier-L mfma-issue vm-wait-M barrier-M"
-            for grp in (0, 1):
-                g = t[:, 4 * grp:4 * grp + 4].mean(dim=(0, 1))
-                print("  group %d cycles per K-tile [%s]: %s  sum %.0f" % (grp, names, " ".join("%.0f" % v for v in g.tolist()), g.sum()))
+            print("  loop (longest workgroups, %d of %d): %.0f cycles, %.2f us, clock %.2f GHz, %d K-tiles -> %.0f cycles per K-tile incl. epilogues; epilogue %.0f cycles per tile (wave 0)" % (
+                len(big), len(e), big[:, 0].mean(), big[:, 1].mean() / 100, big[:, 0].mean() / big[:, 1].mean() / 10, int(big[0, 2]), (big[:, 0] / big[:, 2]).mean(), big[:, 3].mean()))
     elif op == "gemmdual":      # the MLP pairs of a training step: pre | der (fc1 forward, two outputs), dgpre | dgder (fc2 data gradient x GELU')
         M, N, K = int(a[0]), int(a[1]), int(a[2])
         mode = a[3]
