@@ -16,12 +16,20 @@ int mvit_internal_linear_pp(int epi, const void* a, int64_t lda, const void* w, 
                             const float* row_scale, int64_t rps, void* y, void* y2, int64_t ldy, int64_t M, int N, int K, hipStream_t st);
 enum { PP_B16 = 0, PP_GELU16 = 1, PP_GELU_PRE = 2, PP_GELU_DER = 3, PP_F32 = 4, PP_F32_RES = 5, PP_F32_RES_SC = 6, PP_DG_PRE = 7, PP_DG_DER = 8 };
 // Which shapes go to it (MVIT_GEMM_PP=0 / 1 forces off / on for every shape it can take): measured per shape in profiles/r3_gemm_shapes.txt
-static inline bool use_pp(int64_t lda, int64_t M, int N, int K) {
+static inline bool use_pp(int64_t lda, int64_t M, int N, int K, int code) {
     static const char* env = getenv("MVIT_GEMM_PP");
     if (env && env[0] == '0') return false;
     if (!mvit_internal_linear_pp_ok(lda, M, N, K)) return false;
     if (env && env[0] == '1') return true;
-    return M >= 8192;
+    // Measured INSIDE the model, kernel by kernel (profiles/r3_gemm_in_model_ab.txt): in isolation the ping-pong kernel is ahead on every
+    // shape (profiles/r3_gemm_pp_final_ab.txt), inside a step only where the epilogue is short -- 16-bit bias outputs (qkv and the
+    // long-K data gradients: -9 % over a train step), the K <= 512 fp32-residual output (proj) and the two-output fc1 of training.
+    // The GELU and long-K fp32-residual epilogues run under the OTHER workgroup's main loop in the 128 x 192 kernels (two workgroups
+    // per CU) and stay there.
+    if (M < 8192) return false;
+    if (code == PP_DG_PRE || code == PP_DG_DER || code == PP_GELU16) return false;
+    if ((code == PP_F32_RES || code == PP_F32_RES_SC) && (N < 384 || K > 512)) return false;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1158,7 +1166,7 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
         return MVIT_EUNSUPPORTED;
 #define DISPATCH(TA, TO) \
     return launch_linear_mfma<TA, TO>(a, lda, w, bias, residual, ldr, row_scale, rows_per_scale, y, ldy, M, N, K, epilogue, st)
-    if (a_dtype == MVIT_BF16 && (ldy & 7) == 0 && use_pp(lda, M, N, K)) {
+    if (a_dtype == MVIT_BF16 && (ldy & 7) == 0) {
         const bool res = (epilogue & MVIT_EPI_RESIDUAL) != 0, gelu = (epilogue & MVIT_EPI_GELU) != 0;
         int code = -1;
         if (out_dtype == MVIT_BF16 && !res && !row_scale) code = gelu ? PP_GELU16 : PP_B16;
@@ -1166,7 +1174,7 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
             if (res && (ldr & 3) == 0) code = row_scale ? PP_F32_RES_SC : PP_F32_RES;
             else if (!res && !row_scale) code = PP_F32;
         }
-        if (code >= 0)
+        if (code >= 0 && use_pp(lda, M, N, K, code))
             return mvit_internal_linear_pp(code, a, lda, w, (epilogue & MVIT_EPI_BIAS) ? bias : nullptr, residual, ldr, row_scale,
                                            rows_per_scale, y, nullptr, ldy, M, N, K, st);
     }
@@ -1212,7 +1220,7 @@ extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_PERS") == nullptr && getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
-    if (fused && use_pp(lda, M, N, K))
+    if (fused && use_pp(lda, M, N, K, PP_GELU_PRE))
         return mvit_internal_linear_pp(PP_GELU_PRE, a, lda, w, bias, nullptr, 0, nullptr, 0, y, pre, N, M, N, K, as_stream(stream));
     if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_pers<bf16_t, 2>(a, lda, w, bias, pre, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
@@ -1231,7 +1239,7 @@ extern "C" int mvit_linear_dgelu_fwd(const void* a, int64_t lda, const void* w, 
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
-    if (fused && use_pp(lda, M, N, K))
+    if (fused && use_pp(lda, M, N, K, PP_DG_PRE))
         return mvit_internal_linear_pp(PP_DG_PRE, a, lda, w, nullptr, pre, N, row_scale, rows_per_scale, y, nullptr, N, M, N, K, as_stream(stream));
     if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
         return launch_linear_big_t<bf16_t, false, false, 1>(a, lda, w, nullptr, reinterpret_cast<const float*>(pre), N, row_scale,
@@ -1252,7 +1260,7 @@ extern "C" int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
-    if (use_pp(lda, M, N, K))
+    if (use_pp(lda, M, N, K, PP_GELU_DER))
         return mvit_internal_linear_pp(PP_GELU_DER, a, lda, w, bias, nullptr, 0, nullptr, 0, y, dact, N, M, N, K, as_stream(stream));
     return launch_linear_pers<bf16_t, 3>(a, lda, w, bias, dact, 0, nullptr, 0, y, N, M, N, K, MVIT_EPI_BIAS, as_stream(stream));
 }
@@ -1262,7 +1270,7 @@ extern "C" int mvit_linear_dact_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
-    if (use_pp(lda, M, N, K))
+    if (use_pp(lda, M, N, K, PP_DG_DER))
         return mvit_internal_linear_pp(PP_DG_DER, a, lda, w, nullptr, dact, N, row_scale, rows_per_scale, y, nullptr, N, M, N, K, as_stream(stream));
     return launch_linear_big_t<bf16_t, false, false, 2>(a, lda, w, nullptr, reinterpret_cast<const float*>(dact), N, row_scale,
                                                         rows_per_scale, y, N, M, N, K, 0, as_stream(stream));
