@@ -338,6 +338,21 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        # the deferred-reduction queue of the library is process-global state: whatever the body raises (an allocation failure, a
+        # kernel error code), the queue is closed again and the pinned workspaces are dropped before the exception travels on
+        hx = ctx.hx
+        try:
+            return _BlockFn._backward_body(ctx, d_out)
+        except BaseException:
+            if hx._red_keep is not None:
+                try:
+                    hx.L.mvit_reduce_queue_flush(_st())      # closes the queue; what it launches writes into gradients nobody will read
+                finally:
+                    hx._red_keep = None
+            raise
+
+    @staticmethod
+    def _backward_body(ctx, d_out):
         hx, g, blk = ctx.hx, ctx.g, ctx.blk
         L, act, adt = hx.L, hx.act, hx.adt
         if ctx.recompute is not None:          # activation checkpointing: rebuild the block's activations from its input

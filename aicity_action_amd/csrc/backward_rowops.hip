@@ -1,6 +1,8 @@
 // Backward / training-step row kernels (HBM-bound): LayerNorm bwd, GELU fwd/bwd, skip max-pool bwd, column sums
 // (bias gradients), soft-target cross entropy, global grad-norm, AdamW.  All reductions are two-stage and
 // deterministic (no float atomics) unless noted.
+#include <mutex>
+
 #include "common.h"
 
 template <int LPR>
@@ -110,9 +112,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 // and, when there is more than one slice, parks the result in a per-launch scratch row; the slice that ARRIVES LAST for a
 // column block (write-through stores + ticket, L1-bypassing loads on the last arriver: cdna guide G16, sc1 form) adds the parked rows
 // in slice order -- so the summation order is a function of the launch geometry only, never of timing.  Scratch rows and
-// tickets are static device arrays of the library (tickets reset themselves); launches that may overlap in time (the main
-// stream and the weight-gradient side stream) take different scratch slots, handed out round-robin by the launcher.
-#define RED_SLOTS 64
+// tickets are static device arrays of the library (tickets reset themselves).  Slots belong to STREAMS: every stream that
+// reduces gets its own ring of RED_RING slots (red_slot_base below), so two reductions can only share a slot when they are
+// ordered on one stream -- a process-wide round-robin counter let a reduction of one sub-batch stream land on the slot of a
+// still-pending reduction of the other once the counter wrapped (about 130 reductions per backward chain against 64 slots).
+#define RED_SLOTS 128                // 8 stream rings x 16 slots (43 MB of scratch rows)
 #define RED_MAXSLICE 32
 #define RED_MAXW 2624                 // widest table: 27 x 96 pooling-conv weight gradients (2592), padded to 64
 __device__ float g_red_scratch[RED_SLOTS][RED_MAXSLICE][RED_MAXW];
@@ -191,10 +195,48 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(const RedBat
 static RedBatch g_red_queue;
 static bool g_red_queue_on = false;
 static int g_red_units = 0;
-static unsigned g_red_next_slot = 0;
+
+// stream -> ring of RED_RING scratch slots (per device: the scratch arrays are per-device objects).  A ninth stream on one device
+// takes over the least recently used ring after that ring's stream has drained.
+#define RED_RING 16
+#define RED_NRING (RED_SLOTS / RED_RING)
+struct RedRing { hipStream_t st; bool used; unsigned next; unsigned long long stamp; };
+static RedRing g_red_rings[16][RED_NRING];
+static unsigned long long g_red_stamp = 0;
+static std::mutex g_red_mutex;
+static int red_slot_base(hipStream_t st, int nslots, int* base) {          // nslots consecutive slots of st's ring (nslots <= RED_RING)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MVIT_ELAUNCH;
+    std::lock_guard<std::mutex> lock(g_red_mutex);
+    RedRing* rings = g_red_rings[dev];
+    int pick = -1;
+    for (int i = 0; i < RED_NRING; ++i)
+        if (rings[i].used && rings[i].st == st) { pick = i; break; }
+    if (pick < 0) {
+        for (int i = 0; i < RED_NRING && pick < 0; ++i)
+            if (!rings[i].used) pick = i;
+        if (pick < 0) {             // all rings taken: the least recently used one, once its stream has nothing pending
+            pick = 0;
+            for (int i = 1; i < RED_NRING; ++i)
+                if (rings[i].stamp < rings[pick].stamp) pick = i;
+            // (a ninth stream: rare -- the main, weight-gradient, library side, sub-batch and capture streams of a process make five to seven)
+            if (hipStreamQuery(rings[pick].st) != hipSuccess && hipStreamSynchronize(rings[pick].st) != hipSuccess) return MVIT_ELAUNCH;
+        }
+        rings[pick].st = st; rings[pick].used = true; rings[pick].next = 0;
+    }
+    rings[pick].stamp = ++g_red_stamp;
+    if (rings[pick].next + (unsigned)nslots > RED_RING) rings[pick].next = 0;       // consecutive, no wrap inside one launch
+    *base = pick * RED_RING + (int)rings[pick].next;
+    rings[pick].next = (rings[pick].next + (unsigned)nslots) % RED_RING;
+    return MVIT_OK;
+}
 
 static int red_flush(hipStream_t st) {
     if (g_red_queue.n > 0) {
+        int base = 0;
+        const int rc = red_slot_base(st, g_red_queue.n, &base);        // slots are taken on the stream the batch RUNS on
+        if (rc != MVIT_OK) { g_red_queue.n = 0; g_red_units = 0; return rc; }
+        for (int i = 0; i < g_red_queue.n; ++i) g_red_queue.d[i].slot = base + i;
         hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((unsigned)g_red_units), dim3(256), 0, st, g_red_queue);
         g_red_queue.n = 0;
         g_red_units = 0;
@@ -224,7 +266,6 @@ int mvit_internal_reduce_partials(const float* part, int nparts, int width, floa
     if (width > RED_MAXW) return MVIT_EUNSUPPORTED;
     int slices = nparts / 64;
     slices = slices < 1 ? 1 : (slices > RED_MAXSLICE ? RED_MAXSLICE : slices);
-    const int slot = (int)(g_red_next_slot++ % RED_SLOTS);
     if (defer_ok && g_red_queue_on) {
         if (g_red_queue.n == RED_QMAX) {            // full: what is queued goes out now, on this stream
             const int rc = red_flush(st);
@@ -232,10 +273,13 @@ int mvit_internal_reduce_partials(const float* part, int nparts, int width, floa
         }
         RedDesc& d = g_red_queue.d[g_red_queue.n++];
         d.part = part; d.out_a = out_a; d.out_b = out_b; d.nparts = nparts; d.width = width; d.split = split;
-        d.accumulate = accumulate; d.slot = slot; d.nsl = slices; d.first = g_red_units;
+        d.accumulate = accumulate; d.slot = 0; d.nsl = slices; d.first = g_red_units;      // slot: assigned at flush
         g_red_units += ((width + 63) / 64) * slices;
         return MVIT_OK;
     }
+    int slot = 0;
+    const int rc = red_slot_base(st, 1, &slot);
+    if (rc != MVIT_OK) return rc;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, slices), dim3(256), 0, st, part, nparts, width, out_a, out_b, split,
                        accumulate, slot);
     MVIT_LAUNCH_CHECK();

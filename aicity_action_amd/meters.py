@@ -178,8 +178,13 @@ class _IterClock(object):
 
 
 def _check_nan(loss):
+    # NaN: the reference's check (train_net.py:221-223).  An infinite loss is raised too: here the scalars reach the host up to
+    # HIP.STAT_QUEUE_DEPTH iterations late, and what protects the weights meanwhile is the AdamW kernel skipping steps whose
+    # gradient norm is not finite -- with inf (not NaN) the loop would otherwise keep running on skipped updates without a word
     if math.isnan(loss):
         raise RuntimeError("ERROR: Got NaN losses {}".format(datetime.datetime.now()))
+    if math.isinf(loss):
+        raise RuntimeError("ERROR: Got infinite losses {}".format(datetime.datetime.now()))
 
 
 # column order of the train window

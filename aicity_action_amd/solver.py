@@ -182,7 +182,9 @@ class HipAdamW(object):
         grad_scale (float): the gradients carry this loss-scale factor (HipGradScaler): they are unscaled inside the fused
         update, the clip acts on the unscaled norm, and the step is SKIPPED (returns None) when the norm is inf / nan.
         Without a scaler the same guard sits in the AdamW kernel: a non-finite global norm leaves parameters and moments
-        untouched (the loop raises on the NaN loss when the iteration's scalars reach the host, engine.train_epoch)."""
+        untouched (the loop raises on the NaN / infinite loss when the iteration's scalars reach the host, at most
+        HIP.STAT_QUEUE_DEPTH iterations later -- engine.train_epoch, meters._check_nan; ``step_count`` has advanced for those
+        skipped steps, which is moot because the run ends there)."""
         cur = [p.grad.data_ptr() if p.grad is not None else 0 for grp in self.groups for p in grp["params"]]
         if self._table is None or cur != self._grad_ptrs:
             self._build()                                   # grads were re-allocated (e.g. set_to_none): refresh the table

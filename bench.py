@@ -53,13 +53,16 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "window", "loop"])
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"],
+                    help="default: HIP.PRECISION auto = bf16 for the train modes, fp16 (the arithmetic that meets the 1e-3 logit gate) for fwd / window")
     ap.add_argument("--streams", type=int, default=2, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-record", action="store_true", help="train mode: skip the extra eval-forward timing")
     ap.add_argument("--graph", action="store_true", help="loop mode: HIP.GRAPH_STEP (the train step as one replayed hipGraph)")
     args = ap.parse_args()
+    if args.precision is None:
+        args.precision = "bf16" if args.mode in ("train", "loop") else "fp16"
 
     import torch
     import torch.distributed as dist
@@ -293,7 +296,7 @@ def main():
         gmeta = json.loads(bytes(gold["meta"]).decode())
         from aicity_action_amd.utils.synth import synth_clip
         gclip = synth_clip(1, 16, 448, gmeta["clip_seed"]).to(dev)
-        for prec in ("bf16", "fp16"):
+        for prec in ("fp16", "bf16"):        # fp16 first: the arithmetic HIP.PRECISION "auto" runs inference in, and the one that meets the gate
             cfg_f = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", prec, "HIP.STREAMS", args.streams])
             torch.cuda.empty_cache()
             mf = build_model(cfg_f, gpu_id=dev_index).eval()
@@ -304,14 +307,14 @@ def main():
                 for _ in range(5):
                     mf([clip])
                 wins = []
-                for _w in range(2):     # two windows of 20 steps, the faster one reported
+                for _w in range(2):     # two windows of 20 steps; the MEAN is the reported rate (the faster one beside it)
                     barrier()
                     t0 = time.perf_counter()
                     for _ in range(20):
                         mf([clip])
                     barrier()
                     wins.append(time.perf_counter() - t0)
-                fdt = min(wins)
+                fdt = sum(wins) / len(wins)
             ft = torch.tensor([fdt], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(ft, op=dist.ReduceOp.MAX)
@@ -319,13 +322,45 @@ def main():
             cps = world * args.batch * 20 / fdt
             forward_rec[prec] = {"clips_per_s": round(cps, 2), "ms_per_step": round(fdt / 20 * 1e3, 4), "steps": 20, "warmup": 5,
                                  "model_roofline_frac": round(cps / world * GFLOP_PER_CLIP[448] / 1e3 / PEAK_BF16_TFLOPS, 4),
-                                 "windows_ms_per_step": [round(w_ / 20 * 1e3, 4) for w_ in wins],
-                                 "logit_err_vs_golden": float("%.3g" % err),
+                                 "windows_ms_per_step": [round(w_ / 20 * 1e3, 4) for w_ in wins], "protocol": "mean of 2 windows of 20 steps",
+                                 "best_window_clips_per_s": round(world * args.batch * 20 / min(wins), 2),
+                                 "logit_err_vs_golden": float("%.3g" % err), "gate_1e-3_met": bool(err <= 1e-3),
                                  "golden": "tests/golden/mvit_full448.npz (reference CPU fp32 logits, B=1; gate 1e-3)"}
             del mf
         forward_rec["workload"] = "MViTv2-B 16x4 crop=448 eval forward, synthetic clips, BS=%d per GPU, HIP.STREAMS %d (BASELINE configs[1])" % (
             args.batch, args.streams)
         forward_rec["target_frac"] = 0.30
+        met = [p_ for p_ in ("fp16", "bf16") if forward_rec[p_]["gate_1e-3_met"]]
+        forward_rec["headline_dtype"] = met[0] if met else None      # the fastest-listed arithmetic whose logits are within 1e-3 of the reference's
+        forward_rec["headline"] = forward_rec[met[0]] if met else None
+
+    # ---- train mode, N = 1: BASELINE configs[4] beside the headline: sliding-window inference over 3 synthetic 30 s 540p views -------
+    window_rec = None
+    if args.mode == "train" and not args.no_forward_record and args.crop == 448 and world == 1:
+        from aicity_action_amd.inference import SlidingWindowClassifier
+        cfg_w = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.STREAMS", args.streams])     # HIP.PRECISION auto -> fp16 in eval
+        torch.cuda.empty_cache()
+        mw = build_model(cfg_w, gpu_id=dev_index).eval()
+        load_synth_weights(mw, 0)
+        swc = SlidingWindowClassifier(mw, frame_size=448, batch_size=args.batch)
+        gs = torch.Generator(device=dev).manual_seed(99)
+        views = [torch.randint(0, 256, (900, 540, 960, 3), device=dev, dtype=torch.uint8, generator=gs) for _ in range(3)]
+        with torch.no_grad():
+            prec_w = mw.precision                                 # what run() (no_grad) computes in: HIP.PRECISION auto -> fp16
+        res = [swc.run(v) for v in views]                       # warm-up pass (also the shape check below)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            res = [swc.run(v) for v in views]
+        torch.cuda.synchronize()
+        wdt = (time.perf_counter() - t0) / 2
+        window_rec = {"workload": "sliding-window inference: 3 views x 900 frames 540x960 uint8 (synthetic), 57 windows / view of 16 frames (stride 4), "
+                                  "GPU gather + 8-bit INTER_LINEAR resize to 448 + normalise + forward (BASELINE configs[4], one GPU)",
+                      "windows": sum(len(r) for r in res), "last_t1": int(res[0][-1][1]), "clips_per_s": round(3 * 57 / wdt, 2),
+                      "seconds_per_30s_stream_3_views": round(wdt, 4), "seconds_per_view": round(wdt / 3, 4), "precision": prec_w,
+                      "parity_note": "cv2 absent in this image -- front-end parity unpinned (bit-exact against oracle/window_oracle.py only)"}
+        del mw, swc, views
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (BASELINE.md section 4 as far as ~60 s allow) --------
     cpu = None
@@ -421,6 +456,8 @@ def main():
                 "; the step replayed as one hipGraph" if args.graph else "")
         if forward_rec is not None:
             line["forward"] = forward_rec
+        if window_rec is not None:
+            line["window"] = window_rec
         line.update(extra_rooflines)
         print(json.dumps(line))
     if world > 1:

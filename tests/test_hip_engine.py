@@ -246,6 +246,31 @@ def test_multi_stream_train_step_matches_single_stream(tmp_path, precision):
             assert (gr[k] - ref).abs().max().item() <= tol, (ns, k)
 
 
+def test_multi_stream_train_step_full_depth_is_deterministic(tmp_path):
+    """The 16-block model under HIP.TRAIN_STREAMS 2: each sub-batch chain issues ~130 deterministic column reductions (LayerNorm and
+    pooling-conv parameter gradients) whose scratch slots used to come from ONE process-wide counter modulo 64 -- past the wrap
+    two chains on different streams could hold the same slot at the same time.  Slots are per stream now: two runs
+    must agree bit for bit, and the two-stream gradients must match the single-stream ones (tiny model: 8 reductions, no wrap)."""
+    _, meta = load_golden("full224_train")
+    clip = synth_clip(4, meta["num_frames"], meta["crop"], 33).cuda()
+    labels = torch.tensor([2, 11, 5, 16]).cuda()
+    res = []
+    for ns in (1, 2, 2):
+        cfg, model = _make(meta, "bf16", str(tmp_path))
+        cfg.HIP.TRAIN_STREAMS = ns
+        model.train()
+        loss = engine._loss(cfg, model([clip]), labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        del model
+    for k in res[1]:
+        assert torch.equal(res[1][k], res[2][k]), "two-stream runs differ in %s" % k
+        ref = res[0][k]
+        err = (res[1][k] - ref).abs().max().item()
+        assert err <= 3e-2 * max(ref.abs().max().item(), 1e-3), (k, err, ref.abs().max().item())
+
+
 def test_graphed_train_step_reproduces_the_eager_step(tmp_path):
     """HIP.GRAPH_STEP: after two eager iterations engine.train_epoch captures the whole step (forward, loss, backward with its
     side streams, clip + AdamW, top-k) in one hipGraph and replays it with the clip / labels / [lr, bias corrections] refreshed in

@@ -57,3 +57,78 @@ def test_sliding_window_end_to_end_matches_per_window_forward():
         with torch.no_grad():
             ref = model([clip])[0].cpu().numpy()
         assert np.abs(ref - p).max() <= 1e-6
+
+
+def _full448_model():
+    """The BASELINE model at 448 with the default arithmetic (HIP.PRECISION auto -> fp16 in eval), synthetic weights."""
+    import os
+    from conftest import ROOT
+    from aicity_action_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV_448.yaml"), ["NUM_GPUS", 1])
+    model = build_model(cfg).eval()
+    load_synth_weights(model, 0)
+    return model
+
+
+def test_sliding_window_real_size_one_view():
+    """BASELINE configs[4] at its real size: one 30 s 540p view (900 x 540 x 960 x 3 uint8) through the full 448 model, 57 windows in
+    batches of 8 (run_action_classification_temporal_inf.py:74-130, module_wrapper.py:246-253,304-370,384-397): window list =
+    get_proposals(900, 64, 16) with the last window ending at frame 960, float32[18] rows that sum to 1, and three sampled windows
+    equal to the forward of that window alone.  (cv2 is absent from the image: the resize arithmetic is pinned only by the oracle.)"""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (900, 540, 960, 3), device="cuda", dtype=torch.uint8, generator=g)
+    model = _full448_model()
+    with torch.no_grad():
+        assert model.precision == "fp16"          # HIP.PRECISION auto: inference (no_grad, eval) runs the gate-passing fp16 build
+    swc = SlidingWindowClassifier(model, frame_size=448, batch_size=8)
+    res = swc.run(frames)
+    wins = get_proposals(900, 64, 16)
+    assert len(res) == 57 and [(r[0], r[1]) for r in res] == wins and res[-1][1] == 960
+    for t0, t1, p in res:
+        assert p.dtype == np.float32 and p.shape == (18,) and abs(float(p.sum()) - 1.0) < 1e-4 and np.isfinite(p).all()
+    for k in (0, 23, 56):                       # batch positions 0, 7 and the ragged last batch (57 = 7 x 8 + 1)
+        t0, t1, p = res[k]
+        clip = swc.preprocess(frames, [(t0, t1)])
+        with torch.no_grad():
+            ref = model([clip])[0].float().cpu().numpy()
+        assert np.abs(ref - p).max() <= 1e-6, (k, np.abs(ref - p).max())
+
+
+def _window_shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    frames = torch.randint(0, 256, (300, 540, 960, 3), device="cuda", dtype=torch.uint8, generator=g)
+    model = _full448_model()
+    res = SlidingWindowClassifier(model, frame_size=448, batch_size=8).run(frames)        # shard=True: rank-strided windows + one all_gather
+    if rank == 0:
+        q.put([(t0, t1, p.tolist()) for t0, t1, p in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sliding_window_sharded_over_two_ranks_equals_one_rank():
+    """The 8-GPU sharding of configs[4] (windows rank-strided, one all_gather of the [n,18] scores) as two gloo ranks on this GPU, at
+    448: every rank returns the full list, equal to the single-process result window for window."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_window_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=600)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    g = torch.Generator(device="cuda").manual_seed(6)
+    frames = torch.randint(0, 256, (300, 540, 960, 3), device="cuda", dtype=torch.uint8, generator=g)
+    ref = SlidingWindowClassifier(_full448_model(), frame_size=448, batch_size=8).run(frames, shard=False)
+    assert [(a, b) for a, b, _ in got] == [(r[0], r[1]) for r in ref] == get_proposals(300, 64, 16)
+    for (_, _, p), r in zip(got, ref):
+        assert np.abs(np.asarray(p, dtype=np.float32) - r[2]).max() <= 1e-6

@@ -1,6 +1,11 @@
 #!/bin/bash
-# one GPU call: the whole GPU suite, then bench lines with the ping-pong GEMM on (default) and off
+# one GPU call: the whole GPU suite (verbose error lines kept), then the default bench line
 mkdir -p gpurun_out
-(timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8) > gpurun_out/r3_suite.txt; cat gpurun_out/r3_suite.txt
-python bench.py --no-cpu-baseline > gpurun_out/r3_bench_pp1.json 2> gpurun_out/r3_bench_pp1.err; tail -1 gpurun_out/r3_bench_pp1.json | cut -c1-1500
-MVIT_GEMM_PP=0 python bench.py --no-cpu-baseline > gpurun_out/r3_bench_pp0.json 2> gpurun_out/r3_bench_pp0.err; tail -1 gpurun_out/r3_bench_pp0.json | cut -c1-600
+(timeout 3000 python -m pytest tests -x -q -m gpu -s 2>&1 | grep -v "^$" | tail -150) > gpurun_out/r3_suite.txt; tail -12 gpurun_out/r3_suite.txt
+python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err; tail -1 gpurun_out/r3_bench.json | python3 -c '
+import sys, json
+d = json.loads(sys.stdin.read())
+print(d["value"], d["ms_per_step"], d["model_roofline"])
+print(json.dumps(d.get("forward"))[:1800])
+print(json.dumps(d.get("window")))
+print(json.dumps(d.get("cpu_baseline")))'
