@@ -47,25 +47,20 @@ _SIGS = {
     "mvit_head_split_bwd": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_i, c_p]),
     "mvit_window_preprocess": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p]),
     "mvit_layernorm_bwd_workspace_bytes": (c_l, [c_i]),
-    "mvit_layernorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p]),
-    "mvit_layernorm_bwd2": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p]),
-    "mvit_layernorm_bwd3": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p, c_l, c_p]),
+    "mvit_layernorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_f, c_p, c_p, c_l, c_p]),
     "mvit_gelu_fwd": (c_i, [c_p, c_p, c_l, c_i, c_p]),
     "mvit_gelu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     "mvit_linear_gelu_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_dgelu_fwd": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_gelu_fwd_dsave": (c_i, [c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_dact_fwd": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
-    "mvit_linear_wgrad": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     "mvit_linear_wgrad_workspace_bytes": (c_l, [c_i, c_l, c_i, c_l, c_i, c_l, c_i, c_i, c_i]),
-    "mvit_linear_wgrad2": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
+    "mvit_linear_wgrad": (c_i, [c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
     "mvit_colsum_workspace_bytes": (c_l, [c_i]),
     "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),
-    "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i]),
-    "mvit_attention_bwd_workspace_bytes2": (c_l, [c_i, c_i, c_i, c_i]),
+    "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
     "mvit_attention_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
-    "mvit_pool_bwd_workspace_bytes": (c_l, []),
-    "mvit_pool_bwd_workspace_bytes2": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "mvit_pool_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd_train": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_bwd_saved": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
@@ -74,10 +69,8 @@ _SIGS = {
     "mvit_maxpool_skip_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_fwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_bwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "mvit_stem_bwd2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
-    "mvit_stem_bwd3": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),
+    "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),
     "mvit_head_ln_partial": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p]),
     "mvit_head_project_train": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

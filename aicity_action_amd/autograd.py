@@ -101,8 +101,8 @@ class _Ctx(object):
             # deterministic form: per-chunk partial slabs in a workspace, added in chunk order (no float atomics)
             dW, db = self.zeros(N, K), self.zeros(N)
             nb = self.L.mvit_linear_wgrad_workspace_bytes(adt, K, ddt, N, 1 if row_scale is not None else 0, M, N, K, self.act)
-            ws = _ws(nb, a.device) if nb > 0 else None
-            _hip.check(self.L.mvit_linear_wgrad2(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
+            ws = _ws(nb, a.device)
+            _hip.check(self.L.mvit_linear_wgrad(_hip.ptr(a), adt, K, _hip.ptr(dy), ddt, N, _hip.ptr(row_scale), rps, _hip.ptr(dW),
                                                  _hip.ptr(db), M, N, K, self.act, _hip.ptr(ws), nb, _st()), "wgrad")
             return dW, db
         side = self._side()
@@ -179,7 +179,7 @@ class _Ctx(object):
         if emit16 is not None and self.act != _hip.F32 and _LN_EMIT16:
             out16 = torch.empty(dx.shape, dtype=self.adt, device=dx.device)
             sc16, rps16 = emit16
-        _hip.check(self.L.mvit_layernorm_bwd3(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
+        _hip.check(self.L.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(norm.weight), _hip.ptr(dy), ddt, rows_per_dy, dy_scale,
                                               _hip.ptr(base), _hip.ptr(dx), _hip.ptr(dg), _hip.ptr(db), 1, _hip.ptr(ws),
                                               rows, C, norm.eps, _hip.ptr(out16), _hip.ptr(sc16), rps16 if sc16 is not None else 0,
                                               _st()), "ln_bwd")
@@ -224,7 +224,7 @@ class _StemFn(torch.autograd.Function):
         dpt = hx.zeros(*m.pos_embed_temporal.shape)
         nb = hx.L.mvit_stem_bwd_workspace_bytes(B, T, S, hx.act)        # slab form: ordered sums, no float atomics
         ws = _ws(nb, dev)
-        _hip.check(hx.L.mvit_stem_bwd3(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act,
+        _hip.check(hx.L.mvit_stem_bwd(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, hx.act,
                                        _hip.ptr(ws), nb, _st()), "stem_bwd")
         db = hx.colsum(dx.view(-1, 96))
         return None, dW, db, dps, dpt, None
@@ -422,14 +422,14 @@ class _BlockFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty(2, B, h, Lk, 96, dtype=k.dtype, device=dev)
         dk, dv = dkv[0], dkv[1]
-        ws = _ws(L.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk), dev)
+        ws = _ws(L.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk), dev)
         _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(d_o), _hip.ptr(dq),
                                         _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
                    "attention_bwd")
         del d_o
         d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)
-        pws_bytes = max(L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_q[1] if g.stride_q else 1),
-                        L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1]))
+        pws_bytes = max(L.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, g.stride_q[1] if g.stride_q else 1),
+                        L.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, g.stride_kv[1]))
         pws = None if defer else _ws(pws_bytes, dev)      # queued reductions: one workspace per pooling conv, kept until the flush
         pool_grads = []
         kv_batch = "kv" in pool_saved
@@ -455,7 +455,7 @@ class _BlockFn(torch.autograd.Function):
         if kv_batch:      # k and v chains as one set of launches
             xh_kv, rs_kv = pool_saved["kv"]
             dconv_kv = torch.empty_like(dkv)
-            pws2 = _ws(2 * L.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, g.stride_kv[1]), dev)
+            pws2 = _ws(2 * L.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, g.stride_kv[1]), dev)
             if defer:
                 hx._red_keep.append(pws2)
             gk = [hx.zeros(96, 1, 3, 3, 3), hx.zeros(96), hx.zeros(96)]

@@ -770,17 +770,9 @@ static int dkv_splits(int B, int heads, int Lq, int Lk) {
 }
 
 // delta [B*heads*Lq] + (split path) fp32 dK, dV partial slabs [2][splits][B*heads*Lk*96]
-extern "C" int64_t mvit_attention_bwd_workspace_bytes2(int B, int heads, int Lq, int Lk) {
+extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk) {
     const int nz = dkv_splits(B, heads, Lq, Lk);
     return ((int64_t)B * heads * Lq + (nz > 1 ? 2ll * nz : 0ll) * B * heads * Lk * 96) * (int64_t)sizeof(float);
-}
-extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq) {      // upper bound over Lk <= Lq*16 (older callers)
-    int64_t best = 0;
-    for (int Lk = 64; Lk <= 16384; Lk *= 2) {
-        const int64_t v = mvit_attention_bwd_workspace_bytes2(B, heads, Lq, Lk);
-        best = v > best ? v : best;
-    }
-    return best;
 }
 
 // q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.

@@ -309,7 +309,7 @@ static int launch_ln_bwd(const float* x, const float* gamma, const void* dy, int
 // dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
 // dx = (dx_base ? dx_base : 0) + LayerNorm-backward(dy); dx_base may alias dx (in-place accumulate) or be a different buffer
 // (the block backward adds the norm-2 branch onto the incoming stream gradient without cloning it first).
-extern "C" int mvit_layernorm_bwd3(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
+extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
                                    float dy_scale, const float* dx_base, float* dx, float* dgamma, float* dbeta,
                                    int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* dx16,
                                    const float* dx16_row_scale, int64_t dx16_rows_per_scale, void* stream) {
@@ -332,24 +332,6 @@ extern "C" int mvit_layernorm_bwd3(const float* x, const float* gamma, const voi
         default: return MVIT_EUNSUPPORTED;
     }
 #undef LNB
-}
-
-// dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
-// dx = (dx_base ? dx_base : 0) + LayerNorm-backward(dy); dx_base may alias dx (in-place accumulate) or be a different buffer
-// (the block backward adds the norm-2 branch onto the incoming stream gradient without cloning it first).
-extern "C" int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
-                                   float dy_scale, const float* dx_base, float* dx, float* dgamma, float* dbeta,
-                                   int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
-    return mvit_layernorm_bwd3(x, gamma, dy, dy_dtype, rows_per_dy, dy_scale, dx_base, dx, dgamma, dbeta, accumulate_param, workspace,
-                               rows, C, eps, nullptr, nullptr, 0, stream);
-}
-
-// dy_dtype: MVIT_F32 / MVIT_BF16; rows_per_dy > 1 => broadcast mode (dy must be fp32 [rows/rows_per_dy][C]).
-extern "C" int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
-                                  float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                                  int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream) {
-    return mvit_layernorm_bwd2(x, gamma, dy, dy_dtype, rows_per_dy, dy_scale, accumulate_dx ? dx : nullptr, dx, dgamma, dbeta,
-                               accumulate_param, workspace, rows, C, eps, stream);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 //   * bf16 path: MFMA 32x32x16; one workgroup = a 96x96 tile of dW over a chunk of M.  Both operands have M
 //     as the MFMA k dimension, so both fragments are TRANSPOSED reads (ds_read_b64_tr_b16) of row-major
 //     [64 m][96] bf16 slabs; the four waves take one 16-row k-step of every slab each (9 MFMAs/wave/slab) and
-//     add their partial tiles to dW with fp32 atomics (128 B contiguous per half-wave; dW is tiny next to M).
+//     write their partial tiles to the M chunk's slab (128 B contiguous per half-wave), summed in chunk order afterwards.
 //   * fp32 path: exact VALU kernel (parity path).
 // dy may carry a per-sample drop-path factor (row_scale), applied while staging.
 #include <stdlib.h>
@@ -126,9 +126,8 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
         }
     }
     // acc[kb][i]: row n = 32*wave + (i&3) + 8(i>>2) + 4h, col k = 32kb + r  -> 128 contiguous bytes per half-wave
-    // part != nullptr: this M chunk's tile goes to its own slab (plain stores; wgrad_reduce_kernel adds the slabs in chunk
-    // order: bit-reproducible).  part == nullptr: legacy float atomics straight into dW / db.
-    if (part) {
+    // this M chunk's tile goes to its own slab (plain stores; wgrad_reduce_kernel adds the slabs in chunk order: bit-reproducible)
+    {
         float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
@@ -141,18 +140,6 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) oW[(int64_t)N * K + n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h] = bacc[i];
         }
-        return;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-            atomicAdd(dW + (int64_t)n * K + k0 + 32 * kb + r, acc[kb][i]);
-        }
-    if (do_bias && r == 0) {   // every column of bacc holds the row sums
-#pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(db + n0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h, bacc[i]);
     }
 }
 
@@ -165,7 +152,7 @@ __global__ __launch_bounds__(192) void wgrad_mfma_kernel(const TA* __restrict__ 
 // LDS images: 64-byte segments of a row are XOR-permuted so that the four rows a transposing read touches fall in
 // different bank ranges: dy image (256-B rows) seg ^= row&3, a image (384-B rows) seg ^= (row>>1)&1; the DMA applies
 // the permutation to the SOURCE address, the reads to the LDS address.
-// Partial tiles of the M chunks are summed with fp32 atomics (dW zeroed by the caller), db through a ones-MFMA.
+// Partial tiles of the M chunks go to per-chunk slabs summed in chunk order (dW zeroed by the caller), db through a ones-MFMA.
 // ------------------------------------------------------------------------------------------------
 #define WB_BP 128
 #define WB_BQ 192
@@ -349,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
         }
     }
     // acc[pb][qb][i]: row n = n0 + 64wp + 32pb + (i&3) + 8(i>>2) + 4h, col k = k0 + 96wq + 32qb + r -> 128 contiguous bytes
-    if (part) {      // this M chunk's tile to its own slab, plain stores (summed in chunk order by wgrad_reduce_kernel)
+    {      // this M chunk's tile to its own slab, plain stores (summed in chunk order by wgrad_reduce_kernel)
         float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
@@ -370,30 +357,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_big_kernel(const bf16_t* __restr
                     if (n < N) oW[(int64_t)N * K + n] = bacc[pb][i];
                 }
         }
-        return;
-    }
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int kk = k0 + (KHALF ? 0 : 96 * wq) + 32 * qb + r;
-#ifdef WB_ABL
-                if (n < N && kk < K && acc[pb][qb][i] == 12345.678f) dW[(int64_t)n * K + kk] = 0.f;
-#else
-                if (n < N && kk < K) atomicAdd(dW + (int64_t)n * K + kk, acc[pb][qb][i]);
-#endif
-            }
-    if (do_bias && r == 0) {
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = n0 + 64 * wp + 32 * pb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (n < N) atomicAdd(db + n, bacc[pb][i]);
-            }
     }
 }
 
@@ -445,7 +408,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dr[i], ar[j], acc[i][j]);
         }
     }
-    if (part) {
+    {
         float* oW = part + (int64_t)blockIdx.y * ((int64_t)N * K + N);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -455,16 +418,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const float* __restrict_
                 if (n < N && k < K) oW[(int64_t)n * K + k] = acc[i][j];
             }
         if (do_bias && tid < 64 && n0 + tid < N) oW[(int64_t)N * K + n0 + tid] = bsum;
-        return;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + ty * 4 + i, k = k0 + tx * 4 + j;
-            if (n < N && k < K) atomicAdd(dW + (int64_t)n * K + k, acc[i][j]);
-        }
-    if (do_bias && tid < 64 && n0 + tid < N) atomicAdd(db + n0 + tid, bsum);
 }
 
 // dW[i] += sum_c part[c][i] (i < N*K), db[n] += sum_c part[c][N*K + n], chunks added in index order: the fixed-order second stage
@@ -554,7 +508,7 @@ static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd,
     return p;
 }
 
-// fp32 workspace bytes of the deterministic (slab) form of mvit_linear_wgrad2 for this problem; 0 if it has no such form
+// fp32 workspace bytes mvit_linear_wgrad needs for this problem; 0 if the shape is unsupported
 extern "C" int64_t mvit_linear_wgrad_workspace_bytes(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, int has_row_scale, int64_t M,
                                                      int N, int K, int act_dtype) {
     const WgradPlan p = wgrad_plan(a_dtype, lda, dy_dtype, ldd, has_row_scale != 0, M, N, K, act_dtype);
@@ -563,19 +517,20 @@ extern "C" int64_t mvit_linear_wgrad_workspace_bytes(int a_dtype, int64_t lda, i
 }
 
 // dW (and db when given: db[n] += sum_m scale*dy[m][n]) must be zeroed (or hold the value to accumulate onto) by the caller.
-// workspace (>= mvit_linear_wgrad_workspace_bytes): every M chunk writes its partial dW / db to its own slab and a second kernel
-// adds the slabs in chunk order -- bit-reproducible.  workspace == NULL: the chunks meet in fp32 atomics (order-dependent sums).
-extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                                  const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
-                                  int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream) {
+// Every M chunk writes its partial dW / db to its own slab of `workspace` (>= mvit_linear_wgrad_workspace_bytes) and a second kernel
+// adds the slabs in chunk order -- bit-reproducible; there is no float-atomic form.
+extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                                 const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                                 int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream) {
     if (!a || !dy || !dW || M <= 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
     if (row_scale && rows_per_scale <= 0) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
     const WgradPlan p = wgrad_plan(a_dtype, lda, dy_dtype, ldd, row_scale != nullptr, M, N, K, act_dtype);
     if (p.path < 0) return p.path;
     const int64_t stride = (int64_t)N * K + N;
-    float* part = nullptr;
-    if (workspace && !(N & 3) && !(K & 3) && workspace_bytes >= p.nch * stride * (int64_t)sizeof(float)) part = workspace;
+    if ((N & 3) || (K & 3)) return MVIT_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < p.nch * stride * (int64_t)sizeof(float)) return MVIT_EINVAL;
+    float* part = workspace;
     const int mchunk = p.mchunk;
     if (p.path == 0) {
         dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)p.nch);
@@ -610,7 +565,7 @@ extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const
 #undef WG
     }
     MVIT_LAUNCH_CHECK();
-    if (part) {
+    {
         int64_t blocks = ((stride / 4) + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         int nslab = (int)p.nch;
@@ -632,8 +587,3 @@ extern "C" int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const
     return MVIT_OK;
 }
 
-extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                                 const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
-                                 int K, int act_dtype, void* stream) {
-    return mvit_linear_wgrad2(a, a_dtype, lda, dy, dy_dtype, ldd, row_scale, rows_per_scale, dW, db, M, N, K, act_dtype, nullptr, 0, stream);
-}

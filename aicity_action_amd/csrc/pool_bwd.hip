@@ -330,9 +330,8 @@ __global__ __launch_bounds__(1024) void pool_wgrad_kernel(const TA* __restrict__
     }
 }
 
-extern "C" int64_t mvit_pool_bwd_workspace_bytes(void) { return ((int64_t)PB_MAXBLK * 192 + (int64_t)PW_MAXBLK * 2592) * sizeof(float); }
 // geometry-aware size (the tiled LN-backward writes one 192-float partial row per tile workgroup)
-extern "C" int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H, int W, int stride_hw) {
+extern "C" int64_t mvit_pool_bwd_workspace_bytes(int B, int heads, int T, int H, int W, int stride_hw) {
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
     int64_t rows = PB_MAXBLK;
     if (stride_hw == 1) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
@@ -537,7 +536,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     if (stride_hw == 1) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
     if (stride_hw == 2) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
     if (prow < PB_MAXBLK) prow = PB_MAXBLK;
-    float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes2
+    float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes
     const bool tiled = stride_hw == 1 || stride_hw == 2;
     static const bool dgrad_tiled = getenv("MVIT_POOL_DGRAD_GATHER") == nullptr;
     // the conv weight gradient beside the data gradient on the side stream: -0.55 ms per train step when OFF (profiles/
@@ -611,7 +610,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
 // Backward of the k and v pooling convs of a block together (stride 2, saved xhat / rstd; other cases: MVIT_EUNSUPPORTED, use the
 // single form twice): three launches for both tensors -- LayerNorm backward, conv weight gradient, conv data gradient -- each with
 // twice the workgroups of the single form (which at 256 workgroups of 3 waves is latency-bound).  xhat_kv / dout_kv / dconv_kv are
-// [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv [2][...]; workspace >= 2 x mvit_pool_bwd_workspace_bytes2(...).  The per-tensor
+// [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv [2][...]; workspace >= 2 x mvit_pool_bwd_workspace_bytes(...).  The per-tensor
 // sums (d_w, d_gamma, d_beta) are reduced over each tensor's own contiguous partial rows: bit-identical to the single form.
 extern "C" int mvit_pool_conv_ln_bwd_saved_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
                                               const float* w_v, const float* gamma_v, const void* xhat_kv, const float* rstd_kv,
@@ -627,7 +626,7 @@ extern "C" int mvit_pool_conv_ln_bwd_saved_kv(const void* qkv, int64_t ld, int c
     hipStream_t st = as_stream(stream);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int64_t tot_out = (int64_t)B * heads * T * Ho * Wo;            // tokens of ONE tensor
-    int64_t prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;   // rows of mvit_pool_bwd_workspace_bytes2, per tensor
+    int64_t prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;   // rows of mvit_pool_bwd_workspace_bytes, per tensor
     if (prow < PB_MAXBLK) prow = PB_MAXBLK;
     int64_t bs = (tot_out + 63) / 64;
     bs = bs > prow ? prow : bs;

@@ -7,7 +7,7 @@
 
 // ------------------------------------------------------------------------------------------------
 // stem weight gradient (v1, fp32 VALU): persistent workgroups walk 8x8-token tiles; thread = (channel, group of
-// 10 taps) and keeps its 9 planes x 10 taps partial sums in registers; one fp32 atomic per (thread, tap) at the end.
+// 10 taps) and keeps its 9 planes x 10 taps partial sums in registers; they go to the workgroup's own slab at the end.
 // ------------------------------------------------------------------------------------------------
 #define SB_PW 35
 __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict__ clip, const float* __restrict__ dx,
@@ -72,14 +72,13 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const float* __restrict
         }
     }
     if (on) {      // part: this workgroup's own [96][441] slab (plain stores; slab_sum_kernel adds them in workgroup order)
-        float* o = part ? part + (int64_t)blockIdx.x * (96 * 441) : dW;
+        float* o = part + (int64_t)blockIdx.x * (96 * 441);
 #pragma unroll
         for (int p = 0; p < 9; ++p)
 #pragma unroll
             for (int k = 0; k < 10; ++k)
                 if (k < ntap) {
-                    if (part) o[(int64_t)c * 441 + p * 49 + tap0 + k] = acc[p][k];
-                    else atomicAdd(o + (int64_t)c * 441 + p * 49 + tap0 + k, acc[p][k]);
+                    o[(int64_t)c * 441 + p * 49 + tap0 + k] = acc[p][k];
                 }
     }
 }
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __res
                 for (int i = 0; i < 16; ++i) {
                     const int c = 32 * cb + (i & 3) + 8 * (i >> 2) + 4 * h;
                     // part: slab of this row group (the three input-channel workgroups of a group write disjoint columns)
-                    if (part) part[(int64_t)(blockIdx.x / 3) * (96 * 441) + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx] = acc[cb][kb][i];
-                    else atomicAdd(dW + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx, acc[cb][kb][i]);
+                    part[(int64_t)(blockIdx.x / 3) * (96 * 441) + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx] = acc[cb][kb][i];
                 }
         }
     }
@@ -260,8 +258,7 @@ __global__ __launch_bounds__(256) void stem_pos_bwd_kernel(const float* __restri
             float s = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) s += red[rr][threadIdx.x];
-            if (part) part[((int64_t)blockIdx.x * To + t) * 96 + threadIdx.x] = s;
-            else atomicAdd(dpt + t * 96 + threadIdx.x, s);
+            part[((int64_t)blockIdx.x * To + t) * 96 + threadIdx.x] = s;
         }
     }
     if (ok) {
@@ -294,7 +291,7 @@ extern "C" int64_t mvit_stem_bwd_workspace_bytes(int B, int T, int S, int act_dt
     const int64_t pos_blocks = (So * So + 7) / 8;
     return ((int64_t)groups * 96 * 441 + pos_blocks * To * 96) * (int64_t)sizeof(float);
 }
-extern "C" int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
+extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
                               int B, int T, int S, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream) {
     if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (!clip || !dx || !dW || !dpos_spatial || !dpos_temporal || B <= 0 || T <= 0 || S <= 0) return MVIT_EINVAL;
@@ -304,12 +301,9 @@ extern "C" int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, flo
     bool mfma;
     const int groups = stem_wgrad_groups(B, T, S, act_dtype, &mfma);
     const int pos_blocks = (So * So + 7) / 8;
-    float* wpart = nullptr;
-    float* ppart = nullptr;
-    if (workspace && workspace_bytes >= mvit_stem_bwd_workspace_bytes(B, T, S, act_dtype)) {
-        wpart = workspace;
-        ppart = workspace + (int64_t)groups * 96 * 441;
-    }
+    if (!workspace || workspace_bytes < mvit_stem_bwd_workspace_bytes(B, T, S, act_dtype)) return MVIT_EINVAL;
+    float* wpart = workspace;                                   // per-workgroup slabs of dW, summed in workgroup order
+    float* ppart = workspace + (int64_t)groups * 96 * 441;      // partial rows of dpos_temporal
     if (mfma) {
         hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(3 * groups), dim3(192), 0, st, clip, dx, dW, B, T, S, To, So, wpart);
     } else {
@@ -317,22 +311,11 @@ extern "C" int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, flo
         hipLaunchKernelGGL(stem_wgrad_kernel, dim3(groups), dim3(512), 0, st, clip, dx, dW, B, T, S, To, So, tiles_x, tiles_y, wpart);
     }
     MVIT_LAUNCH_CHECK();
-    if (wpart) {
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(42), dim3(256), 0, st, wpart, groups, (int64_t)96 * 441, dW, (int64_t)96 * 441 / 4);
-        MVIT_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(42), dim3(256), 0, st, wpart, groups, (int64_t)96 * 441, dW, (int64_t)96 * 441 / 4);
+    MVIT_LAUNCH_CHECK();
     hipLaunchKernelGGL(stem_pos_bwd_kernel, dim3(pos_blocks), dim3(256), 0, st, dx, dpos_spatial, dpos_temporal, B, To, So * So, ppart);
     MVIT_LAUNCH_CHECK();
-    if (ppart) return mvit_internal_reduce_partials(ppart, pos_blocks, To * 96, dpos_temporal, dpos_temporal, To * 96, 1, st);
-    return MVIT_OK;
-}
-extern "C" int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
-                              int B, int T, int S, int act_dtype, void* stream) {
-    return mvit_stem_bwd3(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, act_dtype, nullptr, 0, stream);
-}
-extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal,
-                             int B, int T, int S, void* stream) {
-    return mvit_stem_bwd3(clip, dx, dW, dpos_spatial, dpos_temporal, B, T, S, MVIT_F32, nullptr, 0, stream);
+    return mvit_internal_reduce_partials(ppart, pos_blocks, To * 96, dpos_temporal, dpos_temporal, To * 96, 1, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -245,7 +245,7 @@ def main():
             if train:
                 do = torch.randn(B_, gm.lq, h_ * 96, device=dev).to(adt)
                 dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-                ws = torch.empty(L.mvit_attention_bwd_workspace_bytes2(B_, h_, gm.lq, gm.lk) // 4, device=dev)
+                ws = torch.empty(L.mvit_attention_bwd_workspace_bytes(B_, h_, gm.lq, gm.lk) // 4, device=dev)
                 ms = timed(lambda: _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse),
                                                                     _hip.ptr(do), _hip.ptr(dq), _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws),
                                                                     B_, h_, gm.lq, gm.lk, 96 ** -0.5, 1, act, st)))

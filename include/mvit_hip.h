@@ -120,20 +120,15 @@ int mvit_head_fwd(const float* x, const float* gamma, const float* beta, const f
  * rows_per_dy consecutive rows and multiplied by dy_scale (backward of the token mean in the head,
  * slowfast/models/video_model_builder.py:1310).  workspace >= mvit_layernorm_bwd_workspace_bytes(C). */
 int64_t mvit_layernorm_bwd_workspace_bytes(int C);
-int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy,
-                       float dy_scale, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                       int accumulate_param, float* workspace, int64_t rows, int C, float eps, void* stream);
-/* Same with an explicit addend: dx = (dx_base ? dx_base : 0) + LN-backward(dy); dx_base may alias dx. */
-int mvit_layernorm_bwd2(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
-                        const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
-                        int64_t rows, int C, float eps, void* stream);
-/* Same, and the resulting dx also leaves as the 16-bit operand of the GEMMs that consume it next: dx16[r][:] = (16-bit)(dx[r][:] *
- * (dx16_row_scale ? dx16_row_scale[r / dx16_rows_per_scale] : 1)) -- bit for bit what mvit_cast_rows_f32_to_bf16 would make of dx
- * (the residual-stream gradient times the next branch's drop-path factor), without reading dx back.  dx16 == NULL: as _bwd2. */
-int mvit_layernorm_bwd3(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
-                        const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
-                        int64_t rows, int C, float eps, void* dx16, const float* dx16_row_scale, int64_t dx16_rows_per_scale,
-                        void* stream);
+/* dx = (dx_base ? dx_base : 0) + LN-backward(dy); dx_base may alias dx (in-place accumulate).  When dx16 != NULL the resulting dx
+ * also leaves as the 16-bit operand of the GEMMs that consume it next: dx16[r][:] = (16-bit)(dx[r][:] * (dx16_row_scale ?
+ * dx16_row_scale[r / dx16_rows_per_scale] : 1)) -- bit for bit what mvit_cast_rows_f32_to_bf16 would make of dx (the
+ * residual-stream gradient times the next branch's drop-path factor), without reading dx back.  dgamma / dbeta leave through the
+ * library's ordered column reduction (no float atomics). */
+int mvit_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, int64_t rows_per_dy, float dy_scale,
+                       const float* dx_base, float* dx, float* dgamma, float* dbeta, int accumulate_param, float* workspace,
+                       int64_t rows, int C, float eps, void* dx16, const float* dx16_row_scale, int64_t dx16_rows_per_scale,
+                       void* stream);
 
 /* erf-GELU as separate elementwise passes (training keeps the pre-activation; slowfast/models/common.py:28). */
 int mvit_gelu_fwd(const void* x, void* y, int64_t n, int act_dtype, void* stream);
@@ -159,19 +154,14 @@ int mvit_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int act_dt
 
 /* dW[N][K] += sum_m dy[m][n] * a[m][k]  (mm backward wrt the weight) and, when db != NULL, db[n] += sum_m dy[m][n]
  * (bias gradient, fused: the dy tile is already on chip).  dy rows may carry the per-sample drop-path factor
- * row_scale[m / rows_per_scale].  dW / db are accumulated into (zero them once per step). */
-int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                      const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
-                      int K, int act_dtype, void* stream);
-/* The same with a caller-provided fp32 workspace of mvit_linear_wgrad_workspace_bytes(...) bytes: every M chunk writes its partial
- * dW / db into its own slab and a second kernel adds the slabs in chunk order, so the result is bit-reproducible (the reference's
- * fp32 step is).  Without a workspace (NULL, or mvit_linear_wgrad) the chunks meet in float atomics and the last
- * bits depend on arrival order. */
+ * row_scale[m / rows_per_scale].  dW / db are accumulated into (zero them once per step).  Every M chunk writes its partial dW / db
+ * into its own slab of `workspace` (>= mvit_linear_wgrad_workspace_bytes(...) bytes) and a second kernel adds the slabs in chunk
+ * order, so the result is bit-reproducible (the reference's fp32 step is).  N and K multiples of 4. */
 int64_t mvit_linear_wgrad_workspace_bytes(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, int has_row_scale, int64_t M, int N,
                                           int K, int act_dtype);
-int mvit_linear_wgrad2(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
-                       const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
-                       int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
+int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const void* dy, int dy_dtype, int64_t ldd,
+                      const float* row_scale, int64_t rows_per_scale, float* dW, float* db, int64_t M, int N,
+                      int K, int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[n] (+)= sum_m row_scale[m/rps] * a[m][n]  (bias gradients).  workspace >= mvit_colsum_workspace_bytes(N). */
 int64_t mvit_colsum_workspace_bytes(int N);
@@ -180,19 +170,17 @@ int mvit_colsum(const void* a, int a_dtype, int64_t M, int N, const float* row_s
 
 /* Backward of mvit_attention_fwd (recompute from LSE; deterministic, no atomics).
  * out / dout: [B][Lq][heads*96]; dq [B][heads][Lq][96]; dk, dv [B][heads][Lk][96]; all act-typed.
- * workspace >= mvit_attention_bwd_workspace_bytes2(B, heads, Lq, Lk)  (delta + fp32 dK/dV partial sums for the
+ * workspace >= mvit_attention_bwd_workspace_bytes(B, heads, Lq, Lk)  (delta + fp32 dK/dV partial sums for the
  * query-split variant used when B*heads*ceil(Lk/128) workgroups cannot fill the chip). */
-int64_t mvit_attention_bwd_workspace_bytes2(int B, int heads, int Lq, int Lk);
-int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq);   /* = ..._bytes2(B, heads, Lq, 6272) */
+int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk);
 int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                        const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
 
 /* Backward of mvit_pool_conv_ln_fwd: dout [B][heads][T*Ho*Wo][96] -> the (which) slice of dqkv [B][T*H*W][ld]
  * (fully overwritten), dw [96][27] (accumulated), dgamma/dbeta.  dconv: scratch shaped like dout.
- * workspace >= mvit_pool_bwd_workspace_bytes2(B, heads, T, H, W, stride_hw). */
-int64_t mvit_pool_bwd_workspace_bytes(void);   /* legacy constant size: valid only for stride_hw > 2 */
-int64_t mvit_pool_bwd_workspace_bytes2(int B, int heads, int T, int H, int W, int stride_hw);
+ * workspace >= mvit_pool_bwd_workspace_bytes(B, heads, T, H, W, stride_hw). */
+int64_t mvit_pool_bwd_workspace_bytes(int B, int heads, int T, int H, int W, int stride_hw);
 int mvit_pool_conv_ln_bwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma,
                           const void* dout, void* dconv, void* dqkv, float* dw, float* dgamma, float* dbeta,
                           int accumulate_param, float* workspace, int B, int heads, int T, int H, int W,
@@ -214,7 +202,7 @@ int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan_off, const
  * same geometry).  Spatial stride 2 only (the eleven blocks whose k / v grid is half the token grid); any other stride returns
  * MVIT_EUNSUPPORTED and the caller uses the single-tensor form twice.  Tensors of the pair are laid out back to back:
  * out_kv / xhat_kv / dout_kv / dconv_kv = [2][B][heads][T*Ho*Wo][96] (k then v), rstd_kv = [2][B*heads*T*Ho*Wo].  The backward
- * needs workspace >= 2 * mvit_pool_bwd_workspace_bytes2(B, heads, T, H, W, 2).  Results are bit-identical to the single form
+ * needs workspace >= 2 * mvit_pool_bwd_workspace_bytes(B, heads, T, H, W, 2).  Results are bit-identical to the single form
  * (each tensor's partial sums are reduced over its own rows, in the same order). */
 int mvit_pool_conv_ln_fwd_train_kv(const void* qkv, int64_t ld, int chan_off_k, const float* w_k, const float* gamma_k,
                                    const float* beta_k, const float* w_v, const float* gamma_v, const float* beta_v, void* out_kv,
@@ -234,19 +222,13 @@ int mvit_maxpool_skip_bwd(const float* x, const float* dy, float* dx, int B, int
 int mvit_maxpool_skip_fwd_idx(const float* x, float* y, void* idx, int B, int T, int H, int W, int C, void* stream);
 int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float* dx, int B, int T, int H, int W, int C, void* stream);
 
-/* Stem backward: dW [96][3][3][7][7], dpos_spatial, dpos_temporal accumulated from dx [B][N][96] (the input clip
- * needs no gradient; the bias gradient is mvit_colsum). */
-int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
-                  int T, int S, void* stream);
-/* Same, with the kernel family chosen by act_dtype (MVIT_F32: exact fp32 VALU; MVIT_BF16: matrix-core weight gradient on
- * 16-bit operands, fp32 accumulate). */
-int mvit_stem_bwd2(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B,
-                   int T, int S, int act_dtype, void* stream);
-/* The same with a caller-provided fp32 workspace (mvit_stem_bwd_workspace_bytes): per-workgroup partial slabs of dW and of
- * dpos_temporal are added in a fixed order, so the three gradients are bit-reproducible; NULL: float atomics. */
+/* Stem backward: dW [96][3][3][7][7], dpos_spatial, dpos_temporal accumulated from dx [B][N][96] (the input clip needs no
+ * gradient; the bias gradient is mvit_colsum).  Kernel family by act_dtype (MVIT_F32: exact fp32 VALU; MVIT_BF16: matrix-core weight
+ * gradient on 16-bit operands, fp32 accumulate).  Per-workgroup partial slabs of dW and of dpos_temporal in `workspace`
+ * (>= mvit_stem_bwd_workspace_bytes) are added in a fixed order: the three gradients are bit-reproducible. */
 int64_t mvit_stem_bwd_workspace_bytes(int B, int T, int S, int act_dtype);
-int mvit_stem_bwd3(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B, int T, int S,
-                   int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
+int mvit_stem_bwd(const float* clip, const float* dx, float* dW, float* dpos_spatial, float* dpos_temporal, int B, int T, int S,
+                  int act_dtype, float* workspace, int64_t workspace_bytes, void* stream);
 
 /* Head, training variant.  mvit_head_ln_partial = stage 1 of mvit_head_fwd (workspace [B][ceil(N/32)][C]);
  * mvit_head_project_train: z = mean * mask (dropout mask holding 0 or 1/(1-p), or NULL), logits = z W^T + b;
@@ -300,7 +282,7 @@ void* mvit_side_stream(void);
 int mvit_side_fork(void* stream);
 int mvit_side_join(void* stream);
 
-/* Deferred parameter-gradient reductions.  mvit_layernorm_bwd2 and mvit_pool_conv_ln_bwd_saved each end in small column-sum
+/* Deferred parameter-gradient reductions.  mvit_layernorm_bwd and mvit_pool_conv_ln_bwd_saved each end in small column-sum
  * launches over a partial table in their workspace (d_gamma / d_beta, conv d_w): eight per block backward, ~11 us apiece for a few
  * microseconds of work.  Between mvit_reduce_queue_begin() and mvit_reduce_queue_flush(stream) those launches are queued instead
  * (up to 16; a full queue flushes itself) and go out as ONE launch on `stream`, which must be ordered after every producer.

@@ -46,8 +46,8 @@ def test_layernorm_bwd(hip_lib, dyt, C, rows):
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
     xd, gd, dyd = x.detach().to(DEV), g.detach().to(DEV), dy.to(DEV)
-    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dyd), dyt, 1, 1.0, _hip.ptr(dx), 1, _hip.ptr(dg),
-                                          _hip.ptr(db), 0, _hip.ptr(ws), rows, C, 1e-6, _st()))
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dyd), dyt, 1, 1.0, _hip.ptr(dx), _hip.ptr(dx), _hip.ptr(dg),
+                                          _hip.ptr(db), 0, _hip.ptr(ws), rows, C, 1e-6, None, None, 0, _st()))     # dx_base = dx: accumulate in place
     _close(dx, x.grad + base, 2e-5)
     _close(dg, g.grad, 2e-5)
     _close(db, b.grad, 2e-5)
@@ -64,8 +64,8 @@ def test_layernorm_bwd_broadcast_mode(hip_lib):
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
     xd, gd, dzd = x.detach().to(DEV), g.detach().to(DEV), dz.to(DEV)
-    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dzd), _hip.F32, N, 1.0 / N, _hip.ptr(dx), 0,
-                                          _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws), B * N, C, 1e-6, _st()))
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dzd), _hip.F32, N, 1.0 / N, None, _hip.ptr(dx),
+                                          _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws), B * N, C, 1e-6, None, None, 0, _st()))
     _close(dx, x.grad, 2e-5)
     _close(dg, g.grad, 2e-5)
     _close(db, b.grad, 2e-5)
@@ -125,8 +125,13 @@ def test_linear_wgrad_and_colsum(hip_lib, act, M, N, K, scaled):
         dbf = torch.zeros(N, device=DEV)
         ad, dyd = a.to(DEV), dy.to(DEV)
         scd = sc.to(DEV) if scaled else None
-        _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(ad), act, K, _hip.ptr(dyd), _hip.F32 if dy_f32 else _hip.BF16, N,
-                                             _hip.ptr(scd), rps if scaled else 0, _hip.ptr(dW), _hip.ptr(dbf), M, N, K, act, _st()))
+        ddt = _hip.F32 if dy_f32 else _hip.BF16
+        nb = hip_lib.mvit_linear_wgrad_workspace_bytes(act, K, ddt, N, 1 if scaled else 0, M, N, K, act)
+        wsw = torch.empty(max(nb // 4, 1), device=DEV)
+        _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(ad), act, K, _hip.ptr(dyd), ddt, N, _hip.ptr(scd), rps if scaled else 0,
+                                             _hip.ptr(dW), _hip.ptr(dbf), M, N, K, act, _hip.ptr(wsw), nb, _st()))
+        assert hip_lib.mvit_linear_wgrad(_hip.ptr(ad), act, K, _hip.ptr(dyd), ddt, N, _hip.ptr(scd), rps if scaled else 0,
+                                         _hip.ptr(dW), _hip.ptr(dbf), M, N, K, act, None, 0, _st()) == -1      # no workspace, no atomics form
         _close(dW, ref + base, 2e-3 if act else 2e-5)
         _close(dbf, dys_m.sum(0), 2e-3 if act else 2e-5)
         ws = torch.empty(hip_lib.mvit_colsum_workspace_bytes(N) // 4, device=DEV)
@@ -161,7 +166,7 @@ def test_attention_bwd(hip_lib, act, B, h, Lq, Lk, add_q):
     lse_ref = torch.logsumexp((qr.detach() @ kr.detach().transpose(-2, -1)) * scale, -1) * 1.4426950408889634
     _close(lse, lse_ref, 1e-2 if act else 1e-5)
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk) // 4, device=DEV)
+    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk) // 4, device=DEV)
     _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod),
                                           _hip.ptr(dq), _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, add_q,
                                           act, _st()))
@@ -193,7 +198,7 @@ def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
     dconv = torch.empty(B, h, Lo, 96, dtype=adt, device=DEV)
     dw = torch.zeros(96, 27, device=DEV)
     dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
-    ws = torch.empty(hip_lib.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, s) // 4, device=DEV)
+    ws = torch.empty(hip_lib.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, s) // 4, device=DEV)
     qd, wd, gd, dod = qkv.to(DEV), w.detach().to(DEV), g.detach().to(DEV), dout.to(DEV)
     _hip.check(hip_lib.mvit_pool_conv_ln_bwd(_hip.ptr(qd), 3 * C, which * C, _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(dod),
                                              _hip.ptr(dconv), _hip.ptr(dqkv), _hip.ptr(dw), _hip.ptr(dg), _hip.ptr(db), 0,
@@ -276,7 +281,9 @@ def test_stem_bwd(hip_lib, B, T, S):
     dW = torch.zeros(96, 441, device=DEV)
     dps, dpt = torch.zeros(So * So, 96, device=DEV), torch.zeros(To, 96, device=DEV)
     cd, dxd = clip.to(DEV), dx.to(DEV)
-    _hip.check(hip_lib.mvit_stem_bwd(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, _st()))
+    nb = hip_lib.mvit_stem_bwd_workspace_bytes(B, T, S, _hip.F32)
+    ws = torch.empty(nb // 4, device=DEV)
+    _hip.check(hip_lib.mvit_stem_bwd(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, T, S, _hip.F32, _hip.ptr(ws), nb, _st()))
     _close(dW, w.grad.reshape(96, 441), 3e-5)
     _close(dps, ps.grad[0], 2e-5)
     _close(dpt, pt.grad[0], 2e-5)
@@ -286,7 +293,9 @@ def test_stem_bwd(hip_lib, B, T, S):
     x2.backward(dx.to(torch.bfloat16).float())
     dW2 = torch.zeros(96, 441, device=DEV)
     dps2, dpt2 = torch.zeros(So * So, 96, device=DEV), torch.zeros(To, 96, device=DEV)
-    _hip.check(hip_lib.mvit_stem_bwd2(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW2), _hip.ptr(dps2), _hip.ptr(dpt2), B, T, S, _hip.BF16, _st()))
+    nb2 = hip_lib.mvit_stem_bwd_workspace_bytes(B, T, S, _hip.BF16)
+    ws2 = torch.empty(nb2 // 4, device=DEV)
+    _hip.check(hip_lib.mvit_stem_bwd(_hip.ptr(cd), _hip.ptr(dxd), _hip.ptr(dW2), _hip.ptr(dps2), _hip.ptr(dpt2), B, T, S, _hip.BF16, _hip.ptr(ws2), nb2, _st()))
     _close(dW2, w2.grad.reshape(96, 441), 3e-5)
     _close(dps2, ps.grad[0], 2e-5)
 
@@ -326,8 +335,8 @@ def test_head_train_and_bwd(hip_lib):
     dx = torch.empty(B * N, C, device=DEV)
     dg, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     ws2 = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
-    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dz), _hip.F32, N, 1.0 / N, _hip.ptr(dx), 0,
-                                          _hip.ptr(dg), _hip.ptr(dbeta), 0, _hip.ptr(ws2), B * N, C, 1e-6, _st()))
+    _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(dz), _hip.F32, N, 1.0 / N, None, _hip.ptr(dx),
+                                          _hip.ptr(dg), _hip.ptr(dbeta), 0, _hip.ptr(ws2), B * N, C, 1e-6, None, None, 0, _st()))
     _close(dx.view(B, N, C), x.grad, 1e-5)
     _close(dg, g.grad, 1e-5)
     _close(dbeta, b.grad, 1e-5)
@@ -392,8 +401,8 @@ def test_cast_transpose(hip_lib, R, C):
 # ---- round-2 entry points: the deterministic / fused forms must agree with the forms they replace -------------------------------
 
 @pytest.mark.parametrize("C,rows,rps", [(96, 1000, 250), (384, 392 * 4, 392), (768, 130, 0)])
-def test_layernorm_bwd3_emits_the_cast_of_its_own_result(hip_lib, C, rows, rps):
-    """mvit_layernorm_bwd3's 16-bit side output is bit for bit mvit_cast_rows_f32_to_bf16 of the dx it wrote, and dx / d_gamma /
+def test_layernorm_bwd_emits_the_cast_of_its_own_result(hip_lib, C, rows, rps):
+    """mvit_layernorm_bwd's 16-bit side output is bit for bit mvit_cast_rows_f32_to_bf16 of the dx it wrote, and dx / d_gamma /
     d_beta are unchanged by asking for it."""
     x = (_rnd(rows, C, seed=61) * 2 + 0.3).to(DEV)
     g = (1 + 0.1 * _rnd(C, seed=62)).to(DEV)
@@ -407,7 +416,7 @@ def test_layernorm_bwd3_emits_the_cast_of_its_own_result(hip_lib, C, rows, rps):
         dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         dx16 = torch.zeros(rows, C, dtype=torch.bfloat16, device=DEV)
         ws = torch.empty(nws, device=DEV)
-        _hip.check(hip_lib.mvit_layernorm_bwd3(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.BF16, 1, 1.0, _hip.ptr(base), _hip.ptr(dx),
+        _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.BF16, 1, 1.0, _hip.ptr(base), _hip.ptr(dx),
                                                _hip.ptr(dg), _hip.ptr(db), 0, _hip.ptr(ws), rows, C, 1e-6,
                                                _hip.ptr(dx16) if emit else None, _hip.ptr(sc) if emit else None, rps if emit and rps else 0, _st()))
         outs.append((dx, dg, db, dx16))
@@ -434,8 +443,8 @@ def test_reduce_queue_gives_the_bits_of_the_immediate_reductions(hip_lib):
             dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
             ws = torch.empty(hip_lib.mvit_layernorm_bwd_workspace_bytes(C) // 4, device=DEV)
             keep.append(ws)                      # the contract: workspaces stay untouched until the flush
-            _hip.check(hip_lib.mvit_layernorm_bwd2(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.F32, 1, 1.0, None, _hip.ptr(dx), _hip.ptr(dg),
-                                                   _hip.ptr(db), 0, _hip.ptr(ws), r, C, 1e-6, _st()))
+            _hip.check(hip_lib.mvit_layernorm_bwd(_hip.ptr(x), _hip.ptr(g), _hip.ptr(dy), _hip.F32, 1, 1.0, None, _hip.ptr(dx), _hip.ptr(dg),
+                                                  _hip.ptr(db), 0, _hip.ptr(ws), r, C, 1e-6, None, None, 0, _st()))
             res.append((dg, db))
         if queued:
             _hip.check(hip_lib.mvit_reduce_queue_flush(_st()))
@@ -449,9 +458,8 @@ def test_reduce_queue_gives_the_bits_of_the_immediate_reductions(hip_lib):
 
 
 @pytest.mark.parametrize("M,N,K", [(6336, 384, 192), (4096, 1152, 384), (64 * 900, 192, 96), (3000, 96, 96)])
-def test_linear_wgrad2_slab_form_is_reproducible_and_matches(hip_lib, M, N, K):
-    """The slab form (workspace) of the weight gradient: equal to the reference product, bit-identical between two runs, and
-    within rounding of the atomics form it replaces."""
+def test_linear_wgrad_is_reproducible_and_matches(hip_lib, M, N, K):
+    """The weight gradient (per-chunk slabs added in chunk order): equal to the reference product and bit-identical between two runs."""
     a = _rnd(M, K, seed=71).to(torch.bfloat16).to(DEV)
     dy = _rnd(M, N, seed=72).to(torch.bfloat16).to(DEV)
     ref = (dy.float().t() @ a.float()).cpu()
@@ -461,16 +469,12 @@ def test_linear_wgrad2_slab_form_is_reproducible_and_matches(hip_lib, M, N, K):
     for _ in range(2):
         dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
         ws = torch.empty(nb // 4, device=DEV)
-        _hip.check(hip_lib.mvit_linear_wgrad2(_hip.ptr(a), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
+        _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(a), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
                                               _hip.BF16, _hip.ptr(ws), nb, _st()))
         outs.append((dW, db))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     _close(outs[0][0], ref, 2e-3)
     _close(outs[0][1], dy.float().sum(0).cpu(), 2e-3)
-    dW2, db2 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
-    _hip.check(hip_lib.mvit_linear_wgrad(_hip.ptr(a), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW2), _hip.ptr(db2), M, N, K,
-                                         _hip.BF16, _st()))
-    _close(dW2, outs[0][0].cpu(), 1e-4)
 
 
 def test_adamw_step_dev_equals_adamw_step(hip_lib):
@@ -537,7 +541,7 @@ def test_pool_kv_pair_form_equals_two_single_calls(hip_lib, act, B, h, T, H, W):
         assert torch.equal(kv[i], o1) and torch.equal(xh[i], x1) and torch.equal(rs[i], r1)
     # ---- backward
     dkv = _rnd(2, B, h, L, 96, seed=90).to(dt).to(DEV)
-    nb = hip_lib.mvit_pool_bwd_workspace_bytes2(B, h, T, H, W, s)
+    nb = hip_lib.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, s)
     dconv = torch.empty_like(dkv)
     dqkv = torch.zeros_like(qkv)
     g = [[torch.zeros(96, 27, device=DEV), torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)] for _ in range(2)]

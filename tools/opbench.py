@@ -121,7 +121,7 @@ def main():
         lse = torch.empty(B, h, Lq, device=dev)
         _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5, 1, _hip.BF16, st))
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        ws = torch.empty(L.mvit_attention_bwd_workspace_bytes2(B, h, Lq, Lk) // 4, device=dev)
+        ws = torch.empty(L.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk) // 4, device=dev)
 
         def fn():
             _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(do), _hip.ptr(dq),
@@ -149,11 +149,11 @@ def main():
         db = torch.zeros(N, device=dev)
 
         nb = L.mvit_linear_wgrad_workspace_bytes(_hip.BF16, K, _hip.BF16, N, 0, M, N, K, _hip.BF16)     # slab form (what training runs)
-        ws = torch.empty(max(nb // 4, 1), device=dev) if not os.environ.get("OPB_WGRAD_ATOMICS") else None
+        ws = torch.empty(max(nb // 4, 1), device=dev)
 
         def fn():
-            _hip.check(L.mvit_linear_wgrad2(_hip.ptr(x), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
-                                            _hip.BF16, _hip.ptr(ws), nb if ws is not None else 0, st))
+            _hip.check(L.mvit_linear_wgrad(_hip.ptr(x), _hip.BF16, K, _hip.ptr(dy), _hip.BF16, N, None, 0, _hip.ptr(dW), _hip.ptr(db), M, N, K,
+                                           _hip.BF16, _hip.ptr(ws), nb, st))
         ms = timeit(fn, reps)
         print("wgrad M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s" % (M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
     elif op == "pool":
