@@ -468,8 +468,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(float* __restri
     }
 }
 
+// wgrad_pp.hip: the ping-pong weight gradient (256 n x 192 k tile per workgroup, 64-row steps over an M chunk)
+bool mvit_internal_wgrad_pp_plan(int64_t lda, int64_t ldd, int64_t M, int N, int K, int64_t* nch, int* mchunk);
+int mvit_internal_wgrad_pp(const void* a, int64_t lda, const void* dy, int64_t ldd, float* part, int64_t M, int N, int K, int64_t nch, int mchunk,
+                           int do_bias, hipStream_t st);
+
 // Launch plan shared by the entry point and the workspace query.
-struct WgradPlan { int path; int64_t nch; int mchunk; };     // path: 0 fp32 VALU, 1 big MFMA tile, 2 96x96 MFMA tile, < 0 error
+struct WgradPlan { int path; int64_t nch; int mchunk; };     // path: 0 fp32 VALU, 1 big MFMA tile, 2 96x96 MFMA tile, 3 ping-pong tile, < 0 error
 static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd, bool scaled, int64_t M, int N, int K, int act_dtype) {
     WgradPlan p = {MVIT_EUNSUPPORTED, 0, 0};
     // M chunk per workgroup: enough workgroups to fill the chip (~2048), at least 1024 rows
@@ -487,6 +492,11 @@ static WgradPlan wgrad_plan(int a_dtype, int64_t lda, int dy_dtype, int64_t ldd,
     }
     if (act_dtype != MVIT_BF16) { p.path = MVIT_EDTYPE; return p; }
     if (N % 96 || K % 96 || (lda & 7) || (ldd & 7)) return p;
+    if (a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !scaled) {
+        int64_t nch_pp = 0;
+        int mch_pp = 0;
+        if (mvit_internal_wgrad_pp_plan(lda, ldd, M, N, K, &nch_pp, &mch_pp)) { p.path = 3; p.nch = nch_pp; p.mchunk = mch_pp; return p; }
+    }
     static const bool use_big = getenv("MVIT_WGRAD_NO_BIG") == nullptr;
     if (use_big && a_dtype == MVIT_BF16 && dy_dtype == MVIT_BF16 && !scaled && N % 32 == 0 && K % 32 == 0 && N >= 32 && K >= 32 && M % 64 == 0 &&
         64 * lda < (1ll << 31) && 64 * ldd < (1ll << 31)) {
@@ -532,7 +542,10 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
     if (!workspace || workspace_bytes < p.nch * stride * (int64_t)sizeof(float)) return MVIT_EINVAL;
     float* part = workspace;
     const int mchunk = p.mchunk;
-    if (p.path == 0) {
+    if (p.path == 3) {
+        const int rc = mvit_internal_wgrad_pp(a, lda, dy, ldd, part, M, N, K, p.nch, mchunk, db != nullptr, st);
+        if (rc != MVIT_OK) return rc;
+    } else if (p.path == 0) {
         dim3 grid(((N + 63) / 64) * ((K + 63) / 64), (unsigned)p.nch);
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
                            rows_per_scale, dW, db, M, N, K, mchunk, part);
