@@ -37,8 +37,8 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_CLIP = {448: 856.45, 224: 127.73}   # SURVEY.md section 8d (2 FLOP/MAC, GEMM + conv terms)
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FWD = "r2_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh)
-TRAFFIC_BWD = "r2_attn_bwd_hbm_traffic.json"
+TRAFFIC_FWD = "r3_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh)
+TRAFFIC_BWD = "r3_attn_bwd_hbm_traffic.json"
 
 
 def attention_flops(geoms, B):

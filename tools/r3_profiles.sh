@@ -3,7 +3,7 @@
 pre=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
-(python -m pytest tests -q -m gpu -s 2>&1 | grep -E "^\[|passed|failed|error" ) > gpurun_out/${pre}_gputest_verbose.txt
+(python -m pytest tests -q -m gpu -s 2>&1 | grep -vE "socket.cpp|^\[Gloo\]" | sed -E "s/^\.+//" | grep -E "\[[a-z0-9_ ]+\]|error|gate|passed|failed|skipped" ) > gpurun_out/${pre}_gputest_verbose.txt
 python bench.py > gpurun_out/${pre}_bench_train_bs8_448.json 2> gpurun_out/${pre}_bench_train.err
 python bench.py --mode loop --no-cpu-baseline > gpurun_out/${pre}_bench_loop.json 2> gpurun_out/${pre}_bench_loop.err
 python bench.py --mode loop --graph --no-cpu-baseline > gpurun_out/${pre}_bench_loop_graph.json 2> gpurun_out/${pre}_bench_loop_graph.err
