@@ -31,6 +31,12 @@ _POOL_FWD_SIDE = os.environ.get("MVIT_POOL_FWD_SIDE", "0") == "1"
 _POOL_KV_BATCH = os.environ.get("MVIT_POOL_KV_BATCH", "1") != "0"
 
 
+def _skip_fused(g, act):
+    """Widening stage-transition blocks (MViTv2-B: 1, 3, 14) take the fused skip path of csrc/skip_pool.hip on the 16-bit builds."""
+    return (g.expand and not g.skip_is_identity and act != _hip.F32 and g.dim_in % 96 == 0 and g.dim_out % 96 == 0
+            and os.environ.get("MVIT_SKIP_FUSE", "1") != "0")
+
+
 def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes) // 4, 1), dtype=torch.float32, device=dev)
 
@@ -307,9 +313,15 @@ class _BlockFn(torch.autograd.Function):
                                         addq, act, _st()), "attention")
         r = x2
         r_full = None
-        if g.expand:
+        if _skip_fused(g, act):
+            # widen + max-pool in one kernel: the full-resolution widened tensor never reaches HBM (csrc/skip_pool.hip)
+            r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
+            r_full = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
+            _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(x2), _hip.ptr(hx.w(blk.proj_max_pool.weight)), _hip.ptr(blk.proj_max_pool.bias),
+                                               _hip.ptr(r), _hip.ptr(r_full), B, T, H, W, Cin, Cout, act, _st()), "proj_maxpool")
+        elif g.expand:
             r = hx.linear(x2, hx.w(blk.proj_max_pool.weight), blk.proj_max_pool.bias, torch.float32)
-        if not g.skip_is_identity:
+        if not g.skip_is_identity and r_full is None:
             r_full = r
             r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
             pool_idx = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
@@ -471,12 +483,22 @@ class _BlockFn(torch.autograd.Function):
         del d_qkv
         # ---- skip path ------------------------------------------------------------------------------------
         d_r = d_y
-        if r_full is not None:
+        extra = []
+        if _skip_fused(g, act):
+            # un-pool + data gradient in one kernel; the un-pooled gradient leaves once, 16 bit, for the weight-gradient GEMM
+            d_x = torch.empty(M, Cin, dtype=torch.float32, device=dev)
+            d16 = torch.empty(M, Cout, dtype=adt, device=dev)
+            _hip.check(L.mvit_proj_maxpool_bwd(_hip.ptr(r_full), _hip.ptr(d_y), _hip.ptr(hx.wt(blk.proj_max_pool.weight)), _hip.ptr(d_x),
+                                               _hip.ptr(d16), B, T, H, W, Cin, Cout, act, _st()), "proj_maxpool_bwd")
+            extra = list(hx.wgrad(x2, d16, Cout, Cin))
+            del d16
+        elif r_full is not None:
             d_rf = torch.empty(M, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_bwd_idx(_hip.ptr(r_full), _hip.ptr(d_r), _hip.ptr(d_rf), B, T, H, W, Cout, _st()), "maxpool_bwd")
             d_r = d_rf
-        extra = []
-        if g.expand:
+        if _skip_fused(g, act):
+            pass
+        elif g.expand:
             dWm, dbm = hx.wgrad(x2, d_r, Cout, Cin)
             d_x = hx.linear(d_r, hx.wt(blk.proj_max_pool.weight), None, torch.float32)
             extra = [dWm, dbm]

@@ -441,9 +441,16 @@ class MViT(nn.Module):
         del q, k, v
         # 5. skip path: channel expand on the un-normed x, then max-pool     attention.py:424-432
         r = x.view(M, Cin)
-        if g.expand:
+        from ..autograd import _skip_fused
+        if _skip_fused(g, act):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
+            rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(r), _hip.ptr(self._w(blk.proj_max_pool.weight, act)),
+                                               _hip.ptr(blk.proj_max_pool.bias), _hip.ptr(rp), None, B, T, H, W, Cin, Cout, act, st),
+                       "proj_maxpool")
+            r = rp
+        elif g.expand:
             r = self._linear(L, st, act, r, _hip.F32, blk.proj_max_pool, torch.float32, M)
-        if not g.skip_is_identity:
+        if not g.skip_is_identity and not _skip_fused(g, act):
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r), _hip.ptr(rp), B, T, H, W, Cout, st), "maxpool")
             r = rp

@@ -267,6 +267,46 @@ def test_maxpool_skip_idx_ties_go_to_the_first_maximum(hip_lib):
     _close(dx2, x.grad, 1e-6)
 
 
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 2, 16, 16, 96, 192), (1, 3, 7, 7, 192, 384), (1, 2, 14, 14, 384, 768), (1, 1, 5, 9, 96, 96),
+                                              (1, 2, 28, 28, 192, 384)])
+def test_proj_maxpool_fused_skip_path_bwd(hip_lib, B, T, H, W, Cin, Cout):
+    """Un-pool + data-gradient GEMM in one kernel: dx bit-identical to mvit_maxpool_skip_bwd_idx followed by mvit_linear_fwd, the
+    16-bit copy of the un-pooled gradient equal to the rounded fp32 one, and dx equal to autograd's on the same rounded operands.
+    Integer-valued x makes ties (several windows choosing one token, first-maximum rule) frequent."""
+    g = torch.Generator().manual_seed(50)
+    x = torch.randint(-2, 3, (B, T * H * W, Cout), generator=g).float()          # the widened tensor the forward pooled
+    dy_shape_probe = F.max_pool3d(x.reshape(B, T, H, W, Cout).permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    Lo = dy_shape_probe.shape[2] * dy_shape_probe.shape[3] * dy_shape_probe.shape[4]
+    dy = _rnd(B, Lo, Cout, seed=51)
+    w = _rnd(Cout, Cin, seed=52, scale=Cout ** -0.5)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    wt = w.t().contiguous().to(DEV).to(torch.bfloat16)                             # [Cin][Cout]
+    M = B * T * H * W
+    y = torch.empty(B, Lo, Cout, device=DEV)
+    idx = torch.empty(B, Lo, Cout, dtype=torch.uint8, device=DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_fwd_idx(_hip.ptr(xd), _hip.ptr(y), _hip.ptr(idx), B, T, H, W, Cout, _st()))
+    grf = torch.empty(M, Cout, device=DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_bwd_idx(_hip.ptr(idx), _hip.ptr(dyd), _hip.ptr(grf), B, T, H, W, Cout, _st()))
+    dx0 = torch.empty(M, Cin, device=DEV)
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(grf), _hip.F32, Cout, _hip.ptr(wt), None, None, Cin, None, 0, _hip.ptr(dx0), _hip.F32, Cin, M,
+                                       Cin, Cout, 0, _hip.BF16, _st()))
+    dx1 = torch.full((M, Cin), float("nan"), device=DEV)
+    d16 = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_proj_maxpool_bwd(_hip.ptr(idx), _hip.ptr(dyd), _hip.ptr(wt), _hip.ptr(dx1), _hip.ptr(d16), B, T, H, W, Cin, Cout,
+                                             _hip.BF16, _st()))
+    assert torch.equal(dx1, dx0)
+    assert torch.equal(d16, grf.to(torch.bfloat16))
+    dx2 = torch.full((M, Cin), float("nan"), device=DEV)                          # without the 16-bit copy
+    _hip.check(hip_lib.mvit_proj_maxpool_bwd(_hip.ptr(idx), _hip.ptr(dyd), _hip.ptr(wt), _hip.ptr(dx2), None, B, T, H, W, Cin, Cout, _hip.BF16,
+                                             _st()))
+    assert torch.equal(dx2, dx0)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool3d(xr.reshape(B, T, H, W, Cout).permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1)).reshape(B, Cout, Lo).transpose(
+        1, 2).backward(dy)
+    ref = xr.grad.reshape(M, Cout).to(torch.bfloat16).float() @ w.to(torch.bfloat16).float()
+    _close(dx1, ref, 1e-5)
+
+
 @pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 2, 448)])
 def test_stem_bwd(hip_lib, B, T, S):
     clip = _rnd(B, 3, T, S, S, seed=25)

@@ -325,6 +325,39 @@ def test_maxpool_skip(hip_lib, B, T, H, W, C):
     assert torch.equal(y.cpu(), ref.contiguous())   # pure selection: bit-exact
 
 
+@pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 2, 16, 16, 96, 192), (1, 3, 7, 7, 192, 384), (1, 2, 14, 14, 384, 768), (1, 1, 5, 9, 96, 96),
+                                              (1, 2, 28, 28, 192, 384)])
+def test_proj_maxpool_fused_skip_path(hip_lib, B, T, H, W, Cin, Cout):
+    """Widening skip path in one kernel (attention.py:424-432): bit-identical to the GEMM + max-pool pair of calls it replaces
+    (values AND recorded arg-max bytes: ragged patches, odd sizes, frame borders), and equal to max_pool3d(linear) on the same
+    bf16-rounded operands."""
+    x = _rnd(B, T * H * W, Cin, seed=40)
+    w = _rnd(Cout, Cin, seed=41, scale=Cin ** -0.5)
+    bias = _rnd(Cout, seed=42, scale=0.1)
+    xd, wd, bd = x.to(DEV), w.to(DEV).to(torch.bfloat16), bias.to(DEV)
+    M = B * T * H * W
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Lo = T * Ho * Wo
+    full = torch.empty(M, Cout, device=DEV)
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(xd), _hip.F32, Cin, _hip.ptr(wd), _hip.ptr(bd), None, Cout, None, 0, _hip.ptr(full), _hip.F32,
+                                       Cout, M, Cout, Cin, _hip.EPI_BIAS, _hip.BF16, _st()))
+    y0 = torch.empty(B, Lo, Cout, device=DEV)
+    i0 = torch.empty(B, Lo, Cout, dtype=torch.uint8, device=DEV)
+    _hip.check(hip_lib.mvit_maxpool_skip_fwd_idx(_hip.ptr(full), _hip.ptr(y0), _hip.ptr(i0), B, T, H, W, Cout, _st()))
+    y1 = torch.full((B, Lo, Cout), float("nan"), device=DEV)
+    i1 = torch.full((B, Lo, Cout), 255, dtype=torch.uint8, device=DEV)
+    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y1), _hip.ptr(i1), B, T, H, W, Cin, Cout,
+                                             _hip.BF16, _st()))
+    assert torch.equal(y1, y0) and torch.equal(i1, i0)
+    y2 = torch.full((B, Lo, Cout), float("nan"), device=DEV)        # inference form: no index output
+    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y2), None, B, T, H, W, Cin, Cout, _hip.BF16,
+                                             _st()))
+    assert torch.equal(y2, y0)
+    ref = F.linear(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias)
+    ref = F.max_pool3d(ref.reshape(B, T, H, W, Cout).permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    _close(y1, ref.reshape(B, Cout, Lo).transpose(1, 2), 1e-5)
+
+
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 16, 224)])
 def test_stem(hip_lib, act, B, T, S):

@@ -128,6 +128,43 @@ def main():
                                             _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, 1, _hip.BF16, st))
         ms = timeit(fn, reps)
         print("attnbwd B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s credited (2x forward)" % (B, h, Lq, Lk, ms * 1e3, 8.0 * B * h * Lq * Lk * 96 / ms / 1e9))
+    elif op == "projpool":      # fused widening skip path (csrc/skip_pool.hip): B T H W Cin Cout [reps]; prints fused vs the unfused pair, fwd and bwd
+        B, T, H, W, Cin, Cout = (int(v) for v in a[:6])
+        reps = int(a[6]) if len(a) > 6 else 20
+        M = B * T * H * W
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        Mo = B * T * Ho * Wo
+        x = torch.randn(M, Cin, device=dev)
+        w = (torch.randn(Cout, Cin, device=dev) * Cin ** -0.5).bfloat16()
+        wt = w.t().contiguous()
+        bias = torch.randn(Cout, device=dev)
+        full = torch.empty(M, Cout, device=dev)
+        y = torch.empty(Mo, Cout, device=dev)
+        idx = torch.empty(Mo, Cout, dtype=torch.uint8, device=dev)
+        dy = torch.randn(Mo, Cout, device=dev)
+        dx = torch.empty(M, Cin, device=dev)
+        d16 = torch.empty(M, Cout, device=dev, dtype=torch.bfloat16)
+
+        def unfused_fwd():
+            _hip.check(L.mvit_linear_fwd(_hip.ptr(x), _hip.F32, Cin, _hip.ptr(w), _hip.ptr(bias), None, Cout, None, 0, _hip.ptr(full), _hip.F32, Cout, M,
+                                         Cout, Cin, _hip.EPI_BIAS, _hip.BF16, st))
+            _hip.check(L.mvit_maxpool_skip_fwd_idx(_hip.ptr(full), _hip.ptr(y), _hip.ptr(idx), B, T, H, W, Cout, st))
+
+        def fused_fwd():
+            _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(y), _hip.ptr(idx), B, T, H, W, Cin, Cout, _hip.BF16, st))
+
+        def unfused_bwd():
+            _hip.check(L.mvit_maxpool_skip_bwd_idx(_hip.ptr(idx), _hip.ptr(dy), _hip.ptr(full), B, T, H, W, Cout, st))
+            _hip.check(L.mvit_linear_fwd(_hip.ptr(full), _hip.F32, Cout, _hip.ptr(wt), None, None, Cin, None, 0, _hip.ptr(dx), _hip.F32, Cin, M, Cin,
+                                         Cout, 0, _hip.BF16, st))
+
+        def fused_bwd():
+            _hip.check(L.mvit_proj_maxpool_bwd(_hip.ptr(idx), _hip.ptr(dy), _hip.ptr(wt), _hip.ptr(dx), _hip.ptr(d16), B, T, H, W, Cin, Cout, _hip.BF16, st))
+        alg_f = M * Cin * 4 + Mo * Cout * 5
+        alg_b = Mo * Cout * 5 + M * Cin * 4 + M * Cout * 2
+        for name, fn, alg in (("fwd unfused", unfused_fwd, alg_f), ("fwd fused", fused_fwd, alg_f), ("bwd unfused", unfused_bwd, alg_b), ("bwd fused", fused_bwd, alg_b)):
+            ms = timeit(fn, reps)
+            print("projpool %s B=%d T=%d %dx%d %d->%d: %.1f us  (fused form's algorithmic bytes %.0f MB -> %.2f TB/s)" % (name, B, T, H, W, Cin, Cout, ms * 1e3, alg / 1e6, alg / ms / 1e9))
     elif op == "stem":
         B = int(a[0]); reps = int(a[1]) if len(a) > 1 else 20
         clip = torch.randn(B, 3, 16, 448, 448, device=dev)
