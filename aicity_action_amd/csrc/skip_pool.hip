@@ -4,12 +4,14 @@
 // Unfused, the widened full-resolution fp32 tensor (tokens x Cout: 616 MB at block 1, B = 8 @448) is written by the GEMM, read
 // by the max pool, and in training written again by the un-pool, read by the data-gradient GEMM and read by the weight-gradient
 // GEMM.  Here it never reaches HBM:
-//   forward : one workgroup owns a 4 x 6 patch of POOLED positions of one frame and 96 output channels; its GEMM rows are the
-//             9 x 13 input tokens under that patch (gathered rows, halo recomputed: the GEMM is 1 % of the kernel), the fp32
-//             products go to an LDS stage and leave as window maxima (+ the arg-max byte per element when training).
-//   backward: the A operand of the data-gradient GEMM dx = unpool(dy) W is built on the fly -- each input token gathers the <= 4
-//             windows it belongs to (one index byte + one gradient each, ATen's first-maximum rule as recorded by the forward) --
-//             and is also emitted once, in the 16-bit type, for the weight-gradient GEMM.
+//   forward : one workgroup owns a 4 x 6 patch of POOLED positions of one frame; its GEMM rows are the 9 x 13 input tokens under
+//             that patch (gathered rows, halo recomputed: the GEMM is 1 % of the kernel), gathered once and resident in LDS while
+//             the workgroup walks the Cout / 96 column tiles; the fp32 products go to an LDS stage and leave as window maxima
+//             (+ the arg-max byte per element when training).
+//   backward: one workgroup owns an 8 x 16 patch of input tokens; the A operand of the data-gradient GEMM dx = unpool(dy) W is
+//             built on chip from the 5 x 9 pooled positions under the patch (one index byte + one gradient per window, ATen's
+//             first-maximum rule as recorded by the forward) and is also emitted once, in the 16-bit type, for the
+//             weight-gradient GEMM.
 // Same MFMA sequence per token as linear_mfma_kernel (96-wide K slabs, 32x32x16, k ascending): results are bit-identical to the
 // unfused pair of calls.
 #include "common.h"
@@ -22,8 +24,7 @@
 #define SP_BN 96
 #define SP_BK 96
 #define SP_ROWB 192                   // bytes per LDS slab row (96 x 16 bit)
-#define SP_LD 100                     // fp32 stage leading dimension (floats)
-#define SP_SMEM (SP_ROWS * SP_LD * 4) // 51200 >= the two slabs (43008)
+#define SP_LD 100                     // backward: fp32 output stage leading dimension (floats), [128][96] = 51200 bytes
 
 // [rows][96] 16-bit slab, 16-byte chunk c of row r at position (c + ((r>>2)&3)) % 12: the 32x32x16 fragment reads are conflict-free
 __device__ __forceinline__ int sp_slab_off(int row, int chunk) {
