@@ -766,12 +766,26 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
     }
 }
 
+// attention_w64.hip
+int attn_fwd_w64_prepare();
+int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads, int Lq, int Lk,
+                        float scale_log2e, int add_q, hipStream_t st);
+
 extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
                                   int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return MVIT_EINVAL;
     hipStream_t st = as_stream(stream);
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (act_dtype == MVIT_BF16) {
+        static const bool w64_env = getenv("MVIT_ATT_W64") && atoi(getenv("MVIT_ATT_W64")) != 0;     // 64 queries per wave (attention_w64.hip)
+        if (w64_env && Lk >= 64) {
+            static bool wattr_done = false;
+            if (!wattr_done) { const int rc = attn_fwd_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
+            const int rc = attn_fwd_w64_launch(q, k, v, out, lse, B, heads, Lq, Lk, scale * 1.44269504088896340736f, add_q, st);
+            if (rc != MVIT_OK) return rc;
+            MVIT_LAUNCH_CHECK();
+            return MVIT_OK;
+        }
         static const bool pipe_env = !(getenv("MVIT_ATT_PIPE") && atoi(getenv("MVIT_ATT_PIPE")) == 0);   // default: software-pipelined kernel
         if (pipe_env) {
             dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
