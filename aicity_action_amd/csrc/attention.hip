@@ -777,8 +777,10 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
     hipStream_t st = as_stream(stream);
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (act_dtype == MVIT_BF16) {
-        static const bool w64_env = getenv("MVIT_ATT_W64") && atoi(getenv("MVIT_ATT_W64")) != 0;     // 64 queries per wave (attention_w64.hip)
-        if (w64_env && Lk >= 64) {
+        // default: 64 queries per wave, one wave per SIMD (attention_w64.hip; +11 % on the model's shapes); MVIT_ATT_W64=0 selects the
+        // 32-query kernels below, which also serve short sequences
+        static const bool w64_env = !(getenv("MVIT_ATT_W64") && atoi(getenv("MVIT_ATT_W64")) == 0);
+        if (w64_env && Lk >= 64 && Lq >= 128) {
             static bool wattr_done = false;
             if (!wattr_done) { const int rc = attn_fwd_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
             const int rc = attn_fwd_w64_launch(q, k, v, out, lse, B, heads, Lq, Lk, scale * 1.44269504088896340736f, add_q, st);
