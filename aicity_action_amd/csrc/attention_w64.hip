@@ -201,37 +201,37 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     // pinned (an empty asm naming its results): without a use the optimiser sinks the arithmetic out of its slot.
     uint32_t pw[2][4][4];
     wf32x2 e_t[3], e_p[3];             // in-flight pair state (three pairs are in flight in the pipelined phases)
-    auto ex_a = [&](f32x16 (&s)[2][2], auto J, auto E, const wf32x2 (&mc2)[2]) {         // t = s * c - m * c
-        constexpr int j = J, e = E, u = e / 4, jj = e % 4, kb = u / 2, sh = u % 2;
+    auto ex_a = [&](f32x16 (&s)[2][2], auto J, auto E, auto K, const wf32x2 (&mc2)[2]) {         // t = s * c - m * c
+        constexpr int j = J, e = E, k = K, u = e / 4, jj = e % 4, kb = u / 2, sh = u % 2;
         // two plain v_fma_f32: beside MFMAs a v_pk_fma_f32 costs more issue time than the two (MI355X_MICROARCH, packed f32 VALU)
-        e_t[e % 3][0] = __builtin_fmaf(s[j][kb][8 * sh + 2 * jj], scale_log2e, mc2[j][0]);
-        e_t[e % 3][1] = __builtin_fmaf(s[j][kb][8 * sh + 2 * jj + 1], scale_log2e, mc2[j][0]);
-        asm volatile("" : "+v"(e_t[e % 3][0]), "+v"(e_t[e % 3][1]));
+        e_t[k][0] = __builtin_fmaf(s[j][kb][8 * sh + 2 * jj], scale_log2e, mc2[j][0]);
+        e_t[k][1] = __builtin_fmaf(s[j][kb][8 * sh + 2 * jj + 1], scale_log2e, mc2[j][0]);
+        asm volatile("" : "+v"(e_t[k][0]), "+v"(e_t[k][1]));
     };
-    auto ex_b0 = [&](auto E) {
-        constexpr int e = E;
-        e_p[e % 3][0] = __builtin_amdgcn_exp2f(e_t[e % 3][0]);
-        asm volatile("" : "+v"(e_p[e % 3][0]));
+    auto ex_b0 = [&](auto K) {
+        constexpr int k = K;
+        e_p[k][0] = __builtin_amdgcn_exp2f(e_t[k][0]);
+        asm volatile("" : "+v"(e_p[k][0]));
     };
-    auto ex_b1 = [&](auto E) {
-        constexpr int e = E;
-        e_p[e % 3][1] = __builtin_amdgcn_exp2f(e_t[e % 3][1]);
-        asm volatile("" : "+v"(e_p[e % 3][1]));
+    auto ex_b1 = [&](auto K) {
+        constexpr int k = K;
+        e_p[k][1] = __builtin_amdgcn_exp2f(e_t[k][1]);
+        asm volatile("" : "+v"(e_p[k][1]));
     };
-    auto ex_c = [&](bf16x8 (&pf)[2][4], auto J, auto E, wf32x2& ps) {                    // row sum, pack; fourth word closes the fragment
-        constexpr int j = J, e = E, u = e / 4, jj = e % 4;
-        ps[0] += e_p[e % 3][0];
-        ps[1] += e_p[e % 3][1];
-        pw[j][u][jj] = pack_bf16x2(e_p[e % 3][0], e_p[e % 3][1]);
+    auto ex_c = [&](bf16x8 (&pf)[2][4], auto J, auto E, auto K, wf32x2& ps) {             // row sum, pack; fourth word closes the fragment
+        constexpr int j = J, e = E, k = K, u = e / 4, jj = e % 4;
+        ps[0] += e_p[k][0];
+        ps[1] += e_p[k][1];
+        pw[j][u][jj] = pack_bf16x2(e_p[k][0], e_p[k][1]);
         asm volatile("" : "+v"(pw[j][u][jj]), "+v"(ps[0]), "+v"(ps[1]));
         if constexpr (jj == 3) {
             const uint4 v = make_uint4(pw[j][u][0], pw[j][u][1], pw[j][u][2], pw[j][u][3]);
             pf[j][u] = *reinterpret_cast<const bf16x8*>(&v);
         }
     };
-    // a whole pair at once (prologue, last tile)
-    auto ex_all = [&](f32x16 (&s)[2][2], bf16x8 (&pf)[2][4], auto J, const wf32x2 (&mc2)[2], wf32x2& ps) {
-        w_for<0, 16>([&](auto E) { ex_a(s, J, E, mc2); ex_b0(E); ex_b1(E); ex_c(pf, J, E, ps); });
+    // pairs E0 .. E1-1 of query block J, one after the other (prologue, last tile)
+    auto ex_range = [&](f32x16 (&s)[2][2], bf16x8 (&pf)[2][4], auto J, auto E0, auto E1, const wf32x2 (&mc2)[2], wf32x2& ps) {
+        w_for<decltype(E0)::value, decltype(E1)::value>([&](auto E) { ex_a(s, J, E, IC<0>{}, mc2); ex_b0(IC<0>{}); ex_b1(IC<0>{}); ex_c(pf, J, E, IC<0>{}, ps); });
     };
     // row maxima of a score tile pair (both 32-key blocks, both wave halves), keys >= Lk of the ragged last tile masked first
     auto tile_max = [&](f32x16 (&s)[2][2], float (&mx)[2]) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
             mc2[j] = wf32x2{mcs, mcs};
         }
         wf32x2 ps = {0.f, 0.f};
-        ex_all(sa, pa, std::integral_constant<int, 0>{}, mc2, ps);       // query block 1 of tile 0 is step 0's phase-1 work
+        ex_range(sa, pa, IC<0>{}, IC<0>{}, IC<16>{}, mc2, ps);      // query block 1 of tile 0 is step 0's phase-1 work
         l_run[0] = ps[0] + ps[1];
     }
     W_SB;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
             dma1(d_base + (pc_ >= 3 ? 16 * W_ROWB : 0), g_off[pc_ % 3], d_dst + 1024 * pc_);
         };
         const uint32_t vb_off = (t & 1) * W_TILE, kb_off = (t & 1) * W_TILE;      // V(t); K(t+2) shares t's parity
-        wf32x2 ps1 = {0.f, 0.f};
+        wf32x2 psA[2] = {{0.f, 0.f}, {0.f, 0.f}};
         if constexpr (NEXT) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // K(t+1) fragments (requested a phase ago)
             w_for<0, 24>([&](auto I) {
@@ -329,45 +329,46 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
                 if constexpr (I < 12) v_read(I, vb_off);
                 else if constexpr ((I & 1) == 0) dma_piece(IC<(I - 12) / 2>{});
                 // GENERATED PHASE1 BEGIN (tools/gen_w64_slots.py)
-                if constexpr (I == 0) { ex_a(so, J1{}, IC<0>{}, mc2); ex_b0(IC<0>{}); ex_a(so, J1{}, IC<1>{}, mc2); }
-                if constexpr (I == 1) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(so, J1{}, IC<2>{}, mc2); }
-                if constexpr (I == 2) { ex_c(pc, J1{}, IC<0>{}, ps1); ex_b1(IC<1>{}); ex_b0(IC<2>{}); }
-                if constexpr (I == 3) { ex_a(so, J1{}, IC<3>{}, mc2); ex_c(pc, J1{}, IC<1>{}, ps1); }
-                if constexpr (I == 4) { ex_b1(IC<2>{}); ex_b0(IC<3>{}); ex_a(so, J1{}, IC<4>{}, mc2); }
-                if constexpr (I == 5) { ex_c(pc, J1{}, IC<2>{}, ps1); ex_b1(IC<3>{}); ex_b0(IC<4>{}); }
-                if constexpr (I == 6) { ex_a(so, J1{}, IC<5>{}, mc2); ex_c(pc, J1{}, IC<3>{}, ps1); }
-                if constexpr (I == 7) { ex_b1(IC<4>{}); ex_b0(IC<5>{}); ex_a(so, J1{}, IC<6>{}, mc2); }
-                if constexpr (I == 8) { ex_c(pc, J1{}, IC<4>{}, ps1); ex_b1(IC<5>{}); ex_b0(IC<6>{}); }
-                if constexpr (I == 9) { ex_a(so, J1{}, IC<7>{}, mc2); ex_c(pc, J1{}, IC<5>{}, ps1); }
-                if constexpr (I == 10) { ex_b1(IC<6>{}); ex_b0(IC<7>{}); ex_a(so, J1{}, IC<8>{}, mc2); }
-                if constexpr (I == 11) { ex_c(pc, J1{}, IC<6>{}, ps1); ex_b1(IC<7>{}); ex_b0(IC<8>{}); }
-                if constexpr (I == 12) { ex_a(so, J1{}, IC<9>{}, mc2); ex_c(pc, J1{}, IC<7>{}, ps1); }
-                if constexpr (I == 13) { ex_b1(IC<8>{}); ex_b0(IC<9>{}); ex_a(so, J1{}, IC<10>{}, mc2); }
-                if constexpr (I == 14) { ex_c(pc, J1{}, IC<8>{}, ps1); ex_b1(IC<9>{}); ex_b0(IC<10>{}); }
-                if constexpr (I == 15) { ex_a(so, J1{}, IC<11>{}, mc2); ex_c(pc, J1{}, IC<9>{}, ps1); }
-                if constexpr (I == 16) { ex_b1(IC<10>{}); ex_b0(IC<11>{}); ex_a(so, J1{}, IC<12>{}, mc2); }
-                if constexpr (I == 17) { ex_c(pc, J1{}, IC<10>{}, ps1); ex_b1(IC<11>{}); ex_b0(IC<12>{}); }
-                if constexpr (I == 18) { ex_a(so, J1{}, IC<13>{}, mc2); ex_c(pc, J1{}, IC<11>{}, ps1); }
-                if constexpr (I == 19) { ex_b1(IC<12>{}); ex_b0(IC<13>{}); ex_a(so, J1{}, IC<14>{}, mc2); }
-                if constexpr (I == 20) { ex_c(pc, J1{}, IC<12>{}, ps1); ex_b1(IC<13>{}); ex_b0(IC<14>{}); }
-                if constexpr (I == 21) { ex_a(so, J1{}, IC<15>{}, mc2); ex_c(pc, J1{}, IC<13>{}, ps1); }
-                if constexpr (I == 22) { ex_b1(IC<14>{}); ex_b0(IC<15>{}); ex_c(pc, J1{}, IC<14>{}, ps1); }
-                if constexpr (I == 23) { ex_b1(IC<15>{}); ex_c(pc, J1{}, IC<15>{}, ps1); }
+                if constexpr (I == 0) { ex_a(so, J1{}, IC<0>{}, IC<0>{}, mc2); ex_b0(IC<0>{}); ex_a(so, J1{}, IC<1>{}, IC<1>{}, mc2); }
+                if constexpr (I == 1) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(so, J1{}, IC<2>{}, IC<2>{}, mc2); }
+                if constexpr (I == 2) { ex_c(pc, J1{}, IC<0>{}, IC<0>{}, psA[1]); ex_b1(IC<1>{}); ex_b0(IC<2>{}); }
+                if constexpr (I == 3) { ex_a(so, J1{}, IC<3>{}, IC<0>{}, mc2); ex_c(pc, J1{}, IC<1>{}, IC<1>{}, psA[1]); }
+                if constexpr (I == 4) { ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_a(so, J1{}, IC<4>{}, IC<1>{}, mc2); }
+                if constexpr (I == 5) { ex_c(pc, J1{}, IC<2>{}, IC<2>{}, psA[1]); ex_b1(IC<0>{}); ex_b0(IC<1>{}); }
+                if constexpr (I == 6) { ex_a(so, J1{}, IC<5>{}, IC<2>{}, mc2); ex_c(pc, J1{}, IC<3>{}, IC<0>{}, psA[1]); }
+                if constexpr (I == 7) { ex_b1(IC<1>{}); ex_b0(IC<2>{}); ex_a(so, J1{}, IC<6>{}, IC<0>{}, mc2); }
+                if constexpr (I == 8) { ex_c(pc, J1{}, IC<4>{}, IC<1>{}, psA[1]); ex_b1(IC<2>{}); ex_b0(IC<0>{}); }
+                if constexpr (I == 9) { ex_a(so, J1{}, IC<7>{}, IC<1>{}, mc2); ex_c(pc, J1{}, IC<5>{}, IC<2>{}, psA[1]); }
+                if constexpr (I == 10) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(so, J1{}, IC<8>{}, IC<2>{}, mc2); }
+                if constexpr (I == 11) { ex_c(pc, J1{}, IC<6>{}, IC<0>{}, psA[1]); ex_b1(IC<1>{}); ex_b0(IC<2>{}); }
+                if constexpr (I == 12) { ex_a(so, J1{}, IC<9>{}, IC<0>{}, mc2); ex_c(pc, J1{}, IC<7>{}, IC<1>{}, psA[1]); }
+                if constexpr (I == 13) { ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_a(so, J1{}, IC<10>{}, IC<1>{}, mc2); }
+                if constexpr (I == 14) { ex_c(pc, J1{}, IC<8>{}, IC<2>{}, psA[1]); ex_b1(IC<0>{}); ex_b0(IC<1>{}); }
+                if constexpr (I == 15) { ex_a(so, J1{}, IC<11>{}, IC<2>{}, mc2); ex_c(pc, J1{}, IC<9>{}, IC<0>{}, psA[1]); }
+                if constexpr (I == 16) { ex_b1(IC<1>{}); ex_b0(IC<2>{}); ex_a(so, J1{}, IC<12>{}, IC<0>{}, mc2); }
+                if constexpr (I == 17) { ex_c(pc, J1{}, IC<10>{}, IC<1>{}, psA[1]); ex_b1(IC<2>{}); ex_b0(IC<0>{}); }
+                if constexpr (I == 18) { ex_a(so, J1{}, IC<13>{}, IC<1>{}, mc2); ex_c(pc, J1{}, IC<11>{}, IC<2>{}, psA[1]); }
+                if constexpr (I == 19) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(so, J1{}, IC<14>{}, IC<2>{}, mc2); }
+                if constexpr (I == 20) { ex_c(pc, J1{}, IC<12>{}, IC<0>{}, psA[1]); ex_b1(IC<1>{}); ex_b0(IC<2>{}); }
+                if constexpr (I == 21) { ex_a(so, J1{}, IC<15>{}, IC<0>{}, mc2); ex_c(pc, J1{}, IC<13>{}, IC<1>{}, psA[1]); }
+                if constexpr (I == 22) { ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_c(pc, J1{}, IC<14>{}, IC<2>{}, psA[1]); }
+                if constexpr (I == 23) { ex_b1(IC<0>{}); ex_c(pc, J1{}, IC<15>{}, IC<0>{}, psA[1]); }
                 // GENERATED PHASE1 END
                 W_SB;
             });
         } else {
             w_for<0, 12>([&](auto I) { v_read(I, vb_off); });
-            ex_all(so, pc, J1{}, mc2, ps1);
+            ex_range(so, pc, J1{}, IC<0>{}, IC<16>{}, mc2, psA[1]);
         }
         (void)d_dst; (void)d_base;
-        l_run[1] += ps1[0] + ps1[1];
+        l_run[0] += psA[0][0] + psA[0][1];
+        l_run[1] += psA[1][0] + psA[1][1];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W_SB;
         W_T(1)
         float alpha[2] = {1.f, 1.f};
         bool moved = false;
-        wf32x2 ps0 = {0.f, 0.f};
+        wf32x2 psB[2] = {{0.f, 0.f}, {0.f, 0.f}};
         float mq[2][4];
         w_for<0, 24>([&](auto I) {
             pv(I, pc);
@@ -405,29 +406,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
             }
             if constexpr (NEXT) {                    // slots 7 .. 23: the 16 pairs of query block 0 of tile t+1
                 // GENERATED PHASE2 BEGIN (tools/gen_w64_slots.py)
-                if constexpr (I == 7) { ex_a(sn, J0{}, IC<0>{}, mc2); ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<1>{}, mc2); ex_b1(IC<0>{}); }
-                if constexpr (I == 8) { ex_b0(IC<1>{}); ex_a(sn, J0{}, IC<2>{}, mc2); ex_c(pn, J0{}, IC<0>{}, ps0); ex_b1(IC<1>{}); }
-                if constexpr (I == 9) { ex_b0(IC<2>{}); ex_a(sn, J0{}, IC<3>{}, mc2); ex_c(pn, J0{}, IC<1>{}, ps0); ex_b1(IC<2>{}); }
-                if constexpr (I == 10) { ex_b0(IC<3>{}); ex_a(sn, J0{}, IC<4>{}, mc2); ex_c(pn, J0{}, IC<2>{}, ps0); }
-                if constexpr (I == 11) { ex_b1(IC<3>{}); ex_b0(IC<4>{}); ex_a(sn, J0{}, IC<5>{}, mc2); ex_c(pn, J0{}, IC<3>{}, ps0); }
-                if constexpr (I == 12) { ex_b1(IC<4>{}); ex_b0(IC<5>{}); ex_a(sn, J0{}, IC<6>{}, mc2); ex_c(pn, J0{}, IC<4>{}, ps0); }
-                if constexpr (I == 13) { ex_b1(IC<5>{}); ex_b0(IC<6>{}); ex_a(sn, J0{}, IC<7>{}, mc2); ex_c(pn, J0{}, IC<5>{}, ps0); }
-                if constexpr (I == 14) { ex_b1(IC<6>{}); ex_b0(IC<7>{}); ex_a(sn, J0{}, IC<8>{}, mc2); ex_c(pn, J0{}, IC<6>{}, ps0); }
-                if constexpr (I == 15) { ex_b1(IC<7>{}); ex_b0(IC<8>{}); ex_a(sn, J0{}, IC<9>{}, mc2); }
-                if constexpr (I == 16) { ex_c(pn, J0{}, IC<7>{}, ps0); ex_b1(IC<8>{}); ex_b0(IC<9>{}); ex_a(sn, J0{}, IC<10>{}, mc2); }
-                if constexpr (I == 17) { ex_c(pn, J0{}, IC<8>{}, ps0); ex_b1(IC<9>{}); ex_b0(IC<10>{}); ex_a(sn, J0{}, IC<11>{}, mc2); }
-                if constexpr (I == 18) { ex_c(pn, J0{}, IC<9>{}, ps0); ex_b1(IC<10>{}); ex_b0(IC<11>{}); ex_a(sn, J0{}, IC<12>{}, mc2); }
-                if constexpr (I == 19) { ex_c(pn, J0{}, IC<10>{}, ps0); ex_b1(IC<11>{}); ex_b0(IC<12>{}); ex_a(sn, J0{}, IC<13>{}, mc2); }
-                if constexpr (I == 20) { ex_c(pn, J0{}, IC<11>{}, ps0); ex_b1(IC<12>{}); ex_b0(IC<13>{}); }
-                if constexpr (I == 21) { ex_a(sn, J0{}, IC<14>{}, mc2); ex_c(pn, J0{}, IC<12>{}, ps0); ex_b1(IC<13>{}); ex_b0(IC<14>{}); }
-                if constexpr (I == 22) { ex_a(sn, J0{}, IC<15>{}, mc2); ex_c(pn, J0{}, IC<13>{}, ps0); ex_b1(IC<14>{}); ex_b0(IC<15>{}); }
-                if constexpr (I == 23) { ex_c(pn, J0{}, IC<14>{}, ps0); ex_b1(IC<15>{}); ex_c(pn, J0{}, IC<15>{}, ps0); }
+                if constexpr (I == 7) { ex_a(sn, J0{}, IC<0>{}, IC<0>{}, mc2); ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<1>{}, IC<1>{}, mc2); ex_b1(IC<0>{}); }
+                if constexpr (I == 8) { ex_b0(IC<1>{}); ex_a(sn, J0{}, IC<2>{}, IC<2>{}, mc2); ex_c(pn, J0{}, IC<0>{}, IC<0>{}, psB[0]); ex_b1(IC<1>{}); }
+                if constexpr (I == 9) { ex_b0(IC<2>{}); ex_a(sn, J0{}, IC<3>{}, IC<0>{}, mc2); ex_c(pn, J0{}, IC<1>{}, IC<1>{}, psB[0]); ex_b1(IC<2>{}); }
+                if constexpr (I == 10) { ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<4>{}, IC<1>{}, mc2); ex_c(pn, J0{}, IC<2>{}, IC<2>{}, psB[0]); }
+                if constexpr (I == 11) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(sn, J0{}, IC<5>{}, IC<2>{}, mc2); ex_c(pn, J0{}, IC<3>{}, IC<0>{}, psB[0]); }
+                if constexpr (I == 12) { ex_b1(IC<1>{}); ex_b0(IC<2>{}); ex_a(sn, J0{}, IC<6>{}, IC<0>{}, mc2); ex_c(pn, J0{}, IC<4>{}, IC<1>{}, psB[0]); }
+                if constexpr (I == 13) { ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<7>{}, IC<1>{}, mc2); ex_c(pn, J0{}, IC<5>{}, IC<2>{}, psB[0]); }
+                if constexpr (I == 14) { ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(sn, J0{}, IC<8>{}, IC<2>{}, mc2); ex_c(pn, J0{}, IC<6>{}, IC<0>{}, psB[0]); }
+                if constexpr (I == 15) { ex_b1(IC<1>{}); ex_b0(IC<2>{}); ex_a(sn, J0{}, IC<9>{}, IC<0>{}, mc2); }
+                if constexpr (I == 16) { ex_c(pn, J0{}, IC<7>{}, IC<1>{}, psB[0]); ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<10>{}, IC<1>{}, mc2); }
+                if constexpr (I == 17) { ex_c(pn, J0{}, IC<8>{}, IC<2>{}, psB[0]); ex_b1(IC<0>{}); ex_b0(IC<1>{}); ex_a(sn, J0{}, IC<11>{}, IC<2>{}, mc2); }
+                if constexpr (I == 18) { ex_c(pn, J0{}, IC<9>{}, IC<0>{}, psB[0]); ex_b1(IC<1>{}); ex_b0(IC<2>{}); ex_a(sn, J0{}, IC<12>{}, IC<0>{}, mc2); }
+                if constexpr (I == 19) { ex_c(pn, J0{}, IC<10>{}, IC<1>{}, psB[0]); ex_b1(IC<2>{}); ex_b0(IC<0>{}); ex_a(sn, J0{}, IC<13>{}, IC<1>{}, mc2); }
+                if constexpr (I == 20) { ex_c(pn, J0{}, IC<11>{}, IC<2>{}, psB[0]); ex_b1(IC<0>{}); ex_b0(IC<1>{}); }
+                if constexpr (I == 21) { ex_a(sn, J0{}, IC<14>{}, IC<2>{}, mc2); ex_c(pn, J0{}, IC<12>{}, IC<0>{}, psB[0]); ex_b1(IC<1>{}); ex_b0(IC<2>{}); }
+                if constexpr (I == 22) { ex_a(sn, J0{}, IC<15>{}, IC<0>{}, mc2); ex_c(pn, J0{}, IC<13>{}, IC<1>{}, psB[0]); ex_b1(IC<2>{}); ex_b0(IC<0>{}); }
+                if constexpr (I == 23) { ex_c(pn, J0{}, IC<14>{}, IC<2>{}, psB[0]); ex_b1(IC<0>{}); ex_c(pn, J0{}, IC<15>{}, IC<0>{}, psB[0]); }
                 // GENERATED PHASE2 END
             }
             W_SB;
         });
         if constexpr (NEXT) {
-            l_run[0] = l_run[0] * alpha[0] + ps0[0] + ps0[1];
+            l_run[0] = l_run[0] * alpha[0] + psB[0][0] + psB[0][1];
             l_run[1] *= alpha[1];
             W_T(2)
 #ifdef W_STAMP

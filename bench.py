@@ -277,7 +277,7 @@ def main():
                     "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": args.batch // sub, "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
-        fwd_rl = rl("attn_fwd_pipe_kernel (%s)" % sfx if act else "attn_fwd_f32_kernel", sum(flops), fwd_ms, per_f,
+        fwd_rl = rl("attn_fwd_w64_kernel (%s)" % sfx if act else "attn_fwd_f32_kernel", sum(flops), fwd_ms, per_f,
                     pmc_traffic(TRAFFIC_FWD, "traffic_bytes_per_launch", "attention_fwd"))
         if train:
             roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b,
