@@ -139,6 +139,11 @@ __global__ __launch_bounds__(192) void attn_bwd_delta_flat_kernel(const bf16_t* 
 // global_load_lds_dwordx4 with the rotation swizzle on the source address (two tiles in flight, one s_barrier per tile).
 // The K image serves both the row reads (S^T = K Q^T) and the transposing reads (dQ^T += K^T dS^T): the latter apply the
 // row's rotation to their own address and are issued as inline asm (no compiler vmcnt(0) in front of them).
+// attention_bwd_w64.hip
+int attn_bwd_dq_w64_prepare();
+int attn_bwd_dq_w64_launch(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, void* dq, int B,
+                           int heads, int Lq, int Lk, float scale, float scale_log2e, int add_q, hipStream_t st);
+
 typedef __attribute__((address_space(1))) const void b_gptr_t;
 typedef __attribute__((address_space(3))) void b_lptr_t;
 #define BQ_STAGES 3
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
     asm volatile("" : "+v"(lse), "+v"(dlt));
+    const float ndlt = -dlt;
 
     // K / V row fragment of k-step ks: row r, 16-B chunk (2ks + h + rot(r)) mod 12 with rot <= 3: k-steps 0..3 never wrap (immediate
     // offsets from one lane address), k-steps 4 and 5 each get their own
@@ -296,13 +302,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 for (int i = 0; i < 16; ++i) {
                     const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
                     s[kb][i] = key < Lk ? 0.f : -INFINITY;
-                    dp[kb][i] = 0.f;
+                    dp[kb][i] = ndlt;
                 }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+                for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = ndlt; }       // dP^T - delta comes out of the MFMA chain
         }
         // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order)
         bf16x8 kf[3], vf[3];
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #define DQ_RD(SL, A, OFF, KB) { kf[SL] = b_rd128<OFF + (KB) * 32 * B_ROWB>(A); vf[SL] = b_rd128<OFF + B_T * B_ROWB + (KB) * 32 * B_ROWB>(A); }
 #define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[SL]), "+v"(vf[SL]) : "n"(N))
 #define DQ_MM(SL, KS, KB) { s[KB] = mfma16(kf[SL], qf[KS], s[KB]); dp[KB] = mfma16(vf[SL], dof[KS], dp[KB]); }
-#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(fmaf(s[KB][I], scale_log2e, -lse)); dsv[KB][I] = p_ * (dp[KB][I] - dlt); }
+#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(fmaf(s[KB][I], scale_log2e, -lse)); dsv[KB][I] = p_ * dp[KB][I]; }
 #define DQ_SB __builtin_amdgcn_sched_barrier(0);
 #define TRQ(A, S16) \
         A[0] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[0] + so); A[1] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[0] + so); \
@@ -775,6 +781,18 @@ extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, 
     return ((int64_t)B * heads * Lq + (nz > 1 ? 2ll * nz : 0ll) * B * heads * Lk * 96) * (int64_t)sizeof(float);
 }
 
+// the 64-query form of pass A by itself (tests, tools): delta = mvit_attention_bwd's workspace head (fp32 [B*heads*Lq])
+extern "C" int mvit_internal_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+                                                  void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q, void* stream) {
+    if (!q || !k || !v || !dout || !lse || !delta || !dq || Lk < 64 || Lq < 1) return MVIT_EINVAL;
+    static bool done = false;
+    if (!done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; done = true; }
+    const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, delta, dq, B, heads, Lq, Lk, scale, scale * 1.44269504088896340736f, add_q, as_stream(stream));
+    if (rc != MVIT_OK) return rc;
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
+
 // q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.
 // dq [B][heads][Lq][96], dk/dv [B][heads][Lk][96] (act-typed).  workspace: fp32 [B*heads*Lq] (delta).
 extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
@@ -811,6 +829,17 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         const bool want_side = side_env ? side_env[0] == '1' : Lk > 2048;
         SideStream* ss = want_side ? side_stream_for_current_device() : nullptr;
         hipStream_t skv = (ss && side_fork(ss, st)) ? ss->side : st;
+        // pass A in the 64-queries-per-wave form (attention_bwd_w64.hip) only on request (MVIT_ATT_DQ_W64=1): it measured 4-12 % behind
+        // the 32-query kernel below (profiles/r3_attn_dq_w64.txt)
+        static const bool dq_w64_env = getenv("MVIT_ATT_DQ_W64") && atoi(getenv("MVIT_ATT_DQ_W64")) != 0;
+        const bool dq_w64 = dq_w64_env && Lk >= 64 && Lq >= 128;
+        if (dq_w64) {
+            static bool wattr_done = false;
+            if (!wattr_done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
+            const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, workspace, dq, B, heads, Lq, Lk, scale, sl2, add_q, st);
+            if (rc != MVIT_OK) return rc;
+            MVIT_LAUNCH_CHECK();
+        }
         dim3 gq((Lq + 127) / 128, B * heads);
         static bool dq_attr_done = false;
         if (!dq_attr_done) {
@@ -819,7 +848,8 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
                 return MVIT_ELAUNCH;
             dq_attr_done = true;
         }
-        if (add_q)
+        if (dq_w64) {}
+        else if (add_q)
             hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
         else

@@ -108,11 +108,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         qi[j] = q_ok[j] ? qi[j] : Lq - 1;
     }
     // Q^T fragments: lane (r, h) holds Q[q0 + 32 j + r][16 ks + 8 h .. + 7]
-    w_for<0, 12>([&](auto I) {
-        constexpr int j = I / 6, ks = I % 6;
-        const uint4 u = *reinterpret_cast<const uint4*>(Qb + (int64_t)qi[j] * 96 + 16 * ks + 8 * h);
-        w_qput<WA_Q + 4 * I>(u);
-    });
+    {   // all twelve fragment loads in flight together, then the ACC writes
+        uint4 uq[12];
+#pragma unroll
+        for (int I = 0; I < 12; ++I) uq[I] = *reinterpret_cast<const uint4*>(Qb + (int64_t)qi[I / 6] * 96 + 16 * (I % 6) + 8 * h);
+        w_for<0, 12>([&](auto I) { w_qput<WA_Q + 4 * I>(uq[I]); });
+    }
 
     // LDS-DMA: waves 0, 1 move K tiles, waves 2, 3 V tiles, six 1-KiB pieces each (layout and swizzle as in attention.hip)
     const bool is_v = wave >= 2;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         if constexpr (jj == 3) {
             const uint4 v = make_uint4(pw[j][u][0], pw[j][u][1], pw[j][u][2], pw[j][u][3]);
             pf[j][u] = *reinterpret_cast<const bf16x8*>(&v);
+            asm volatile("" : "+v"(pf[j][u]));        // the fragment exists from here on: no register copy lands in front of the asm MFMA reading it
         }
     };
     // pairs E0 .. E1-1 of query block J, one after the other (prologue, last tile)

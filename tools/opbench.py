@@ -137,6 +137,11 @@ def main():
                                             _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, 1, _hip.BF16, st))
         ms = timeit(fn, reps)
         print("attnbwd B=%d h=%d Lq=%d Lk=%d: %.1f us  %.1f TFLOP/s credited (2x forward)" % (B, h, Lq, Lk, ms * 1e3, 8.0 * B * h * Lq * Lk * 96 / ms / 1e9))
+        if os.environ.get("Y_STAMP"):        # library built with -DY_STAMP (attention_bwd_w64.hip): per-phase cycles per tile in the first floats of each wave's dQ rows
+            fn(); torch.cuda.synchronize()
+            t = dq.view(B * h, Lq, 96)[:, :(Lq // 256) * 256].reshape(B * h, Lq // 256, 4, 64 * 96)[..., :10].contiguous().view(torch.float32)[..., :5]
+            m = t.float().mean(dim=(0, 1, 2)).tolist()
+            print("dq w64 cycles per tile (wait+barrier+dma, A, B, C, D):", [round(x, 1) for x in m], "sum", round(sum(m), 1))
     elif op == "projpool":      # fused widening skip path (csrc/skip_pool.hip): B T H W Cin Cout [reps]; prints fused vs the unfused pair, fwd and bwd
         B, T, H, W, Cin, Cout = (int(v) for v in a[:6])
         reps = int(a[6]) if len(a) > 6 else 20

@@ -36,3 +36,9 @@ MVIT_GEMM_PP=1 tools/pmc.sh ${pre}_pmc_fc1 linear_pp -- gemm 50176 1536 384 bg 1
 MVIT_GEMM_PP=0 tools/pmc.sh ${pre}_pmc_fc1o linear_pers -- gemm 50176 1536 384 bg 10 > gpurun_out/${pre}_pmc_gemm_128x192_fc1.txt 2>&1
 MVIT_GEMM_PP=1 tools/pmc.sh ${pre}_pmc_fc2 linear_pp -- gemm 50176 384 1536 b 10 > gpurun_out/${pre}_pmc_gemm_pp_fc2_plain.txt 2>&1
 rm -rf gpurun_out/${pre}_pmc_fc1 gpurun_out/${pre}_pmc_fc1o gpurun_out/${pre}_pmc_fc2
+# attention forward (64-query kernel): issue counters, kernel alone against the 32-query kernels; skip path op pairs; streams
+tools/pmc.sh ${pre}_pmc_w64 attn_fwd_w64 -- attn 8 4 6272 1568 10 > gpurun_out/${pre}_pmc_attn_fwd_w64.txt 2>&1
+rm -rf gpurun_out/${pre}_pmc_w64
+(for w in 0 1; do for shp in "8 1 100352 1568 10" "8 2 25088 1568 20" "8 4 6272 1568 50" "8 8 1568 1568 50"; do echo "MVIT_ATT_W64=$w: $(MVIT_ATT_W64=$w python3 tools/opbench.py attn $shp 2>&1 | tail -1)"; done; done) > gpurun_out/${pre}_attn_w64_alone.txt 2>&1
+(python3 tools/opbench.py projpool 8 8 112 112 96 192 20; python3 tools/opbench.py projpool 8 8 56 56 192 384 20; python3 tools/opbench.py projpool 8 8 28 28 384 768 20) 2>&1 | grep projpool > gpurun_out/${pre}_skip_path_ops.txt
+(for st in 1 2 3; do echo "HIP.STREAMS $st fwd fp16: $(python bench.py --mode fwd --streams $st --no-cpu-baseline --steps 40 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"; done) > gpurun_out/${pre}_fwd_streams.txt 2>&1
