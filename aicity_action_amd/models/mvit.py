@@ -289,17 +289,18 @@ class MViT(nn.Module):
             # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
             return forward_with_grad(self, x, return_logits)
-        ns = self.eval_streams
-        if ns > 1 and x.shape[0] >= 2 * ns:
+        ns = min(self.eval_streams, x.shape[0] // 2)        # at least two clips per sub-batch
+        if ns > 1:
             return self._forward_streams(x, return_logits, ns)
         return self._forward_hip(x, return_logits)
 
     @property
     def eval_streams(self):
-        """HIP.STREAMS (default 2): inference batches are processed as this many sub-batches on separate HIP streams, so one
-        sub-batch's kernels fill the partially occupied last wave of workgroups of the other's (+7 % at B=8 @448)."""
+        """HIP.STREAMS (default 3): inference batches are processed as this many sub-batches on separate HIP streams, so one
+        sub-batch's kernels fill the partially occupied last wave of workgroups of the others' (two streams +7 % at B=8 @448, three another
+        +1 ... 4 %: profiles/r3_final2_fwd_streams.txt)."""
         hip = getattr(self.cfg, "HIP", None)
-        return int(getattr(hip, "STREAMS", 2)) if hip is not None else 2
+        return int(getattr(hip, "STREAMS", 3)) if hip is not None else 3
 
     @property
     def train_streams(self):

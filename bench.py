@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
     ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"],
                     help="default: HIP.PRECISION auto = bf16 for the train modes, fp16 (the arithmetic that meets the 1e-3 logit gate) for fwd / window")
-    ap.add_argument("--streams", type=int, default=2, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
+    ap.add_argument("--streams", type=int, default=3, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-record", action="store_true", help="train mode: skip the extra eval-forward timing")
@@ -229,10 +229,13 @@ def main():
 
         fwd_ms, bwd_ms, per_f, per_b = 0.0, 0.0, [], []
         # the launches of the timed region: inference runs HIP.STREAMS sub-batches, so each attention launch covers B / streams clips
-        sub = args.streams if (not train and args.streams > 1 and args.batch >= 2 * args.streams) else 1
-        flops = [f / sub for f in flops]
+        # (uneven splits -- 8 clips on 3 streams = 3, 3, 2 -- are timed on the larger launch; `achieved` is a rate, `launches` counts all)
+        sub = min(args.streams, args.batch // 2) if not train else 1
+        sub = sub if sub > 1 else 1
+        clips_pl = -(-args.batch // sub)
+        flops = [f * clips_pl / args.batch for f in flops]
         for gm, fl in zip(core.geoms, flops):
-            B_, h_ = args.batch // sub, gm.heads
+            B_, h_ = clips_pl, gm.heads
             q = torch.randn(B_, h_, gm.lq, 96, device=dev).to(adt)
             k = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
             v = torch.randn(B_, h_, gm.lk, 96, device=dev).to(adt)
@@ -265,7 +268,7 @@ def main():
                 return None
             try:
                 doc = json.load(open(path))
-                rec = doc["by_clips_per_launch"].get(str(args.batch // sub))
+                rec = doc["by_clips_per_launch"].get(str(clips_pl))
                 traffic_src[tag] = {"file": "profiles/" + fname, "measured_at_commit": doc.get("measured_at_commit", "unrecorded")}
                 return round(float(rec[key]), 0) if rec else None
             except Exception:
@@ -274,7 +277,7 @@ def main():
         def rl(name, tot_flops, tot_ms, per_block, traffic=None):
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": args.batch // sub, "avg_launch_ms": round(tot_ms / len(flops), 4),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": clips_pl, "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
         fwd_rl = rl("attn_fwd_w64_kernel (%s)" % sfx if act else "attn_fwd_f32_kernel", sum(flops), fwd_ms, per_f,

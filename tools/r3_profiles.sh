@@ -24,7 +24,8 @@ for m in train fwd; do
 done
 # HBM traffic of the attention kernels (PMC, separate passes)
 rm -rf gpurun_out/traffic
-MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd4_hbm_traffic.json --mode fwd --precision bf16 > /dev/null 2>&1
+# (three sub-batch streams: 8 clips run as 3, 3, 2; --batch 9 makes every launch a 3-clip one, the size bench.py times)
+MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd3_hbm_traffic.json --mode fwd --precision bf16 --batch 9 > /dev/null 2>&1
 rm -rf gpurun_out/traffic
 MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd8_hbm_traffic.json --mode fwd --precision bf16 --streams 1 > /dev/null 2>&1
 rm -rf gpurun_out/traffic
@@ -41,4 +42,4 @@ tools/pmc.sh ${pre}_pmc_w64 attn_fwd_w64 -- attn 8 4 6272 1568 10 > gpurun_out/$
 rm -rf gpurun_out/${pre}_pmc_w64
 (for w in 0 1; do for shp in "8 1 100352 1568 10" "8 2 25088 1568 20" "8 4 6272 1568 50" "8 8 1568 1568 50"; do echo "MVIT_ATT_W64=$w: $(MVIT_ATT_W64=$w python3 tools/opbench.py attn $shp 2>&1 | tail -1)"; done; done) > gpurun_out/${pre}_attn_w64_alone.txt 2>&1
 (python3 tools/opbench.py projpool 8 8 112 112 96 192 20; python3 tools/opbench.py projpool 8 8 56 56 192 384 20; python3 tools/opbench.py projpool 8 8 28 28 384 768 20) 2>&1 | grep projpool > gpurun_out/${pre}_skip_path_ops.txt
-(for st in 1 2 3; do echo "HIP.STREAMS $st fwd fp16: $(python bench.py --mode fwd --streams $st --no-cpu-baseline --steps 40 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"; done) > gpurun_out/${pre}_fwd_streams.txt 2>&1
+(for st in 1 2 3 4; do echo "HIP.STREAMS $st fwd fp16: $(python bench.py --mode fwd --streams $st --no-cpu-baseline --steps 40 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"; done) > gpurun_out/${pre}_fwd_streams.txt 2>&1
