@@ -69,7 +69,7 @@ _SIGS = {
     "mvit_maxpool_skip_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_fwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_maxpool_skip_bwd_idx": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "mvit_proj_maxpool_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_proj_maxpool_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_proj_maxpool_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
     "mvit_stem_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),

@@ -316,9 +316,12 @@ class _BlockFn(torch.autograd.Function):
         if _skip_fused(g, act):
             # widen + max-pool in one kernel: the full-resolution widened tensor never reaches HBM (csrc/skip_pool.hip)
             r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
-            r_full = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
+            pool_idx = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
+            x16 = torch.empty(M, Cin, dtype=adt, device=dev)          # the block input rounded once: operand of the weight gradient
             _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(x2), _hip.ptr(hx.w(blk.proj_max_pool.weight)), _hip.ptr(blk.proj_max_pool.bias),
-                                               _hip.ptr(r), _hip.ptr(r_full), B, T, H, W, Cin, Cout, act, _st()), "proj_maxpool")
+                                               _hip.ptr(r), _hip.ptr(pool_idx), _hip.ptr(x16), B, T, H, W, Cin, Cout, act, _st()),
+                       "proj_maxpool")
+            r_full = (pool_idx, x16)
         elif g.expand:
             r = hx.linear(x2, hx.w(blk.proj_max_pool.weight), blk.proj_max_pool.bias, torch.float32)
         if not g.skip_is_identity and r_full is None:
@@ -488,9 +491,11 @@ class _BlockFn(torch.autograd.Function):
             # un-pool + data gradient in one kernel; the un-pooled gradient leaves once, 16 bit, for the weight-gradient GEMM
             d_x = torch.empty(M, Cin, dtype=torch.float32, device=dev)
             d16 = torch.empty(M, Cout, dtype=adt, device=dev)
-            _hip.check(L.mvit_proj_maxpool_bwd(_hip.ptr(r_full), _hip.ptr(d_y), _hip.ptr(hx.wt(blk.proj_max_pool.weight)), _hip.ptr(d_x),
+            pool_idx, x16 = r_full
+            _hip.check(L.mvit_proj_maxpool_bwd(_hip.ptr(pool_idx), _hip.ptr(d_y), _hip.ptr(hx.wt(blk.proj_max_pool.weight)), _hip.ptr(d_x),
                                                _hip.ptr(d16), B, T, H, W, Cin, Cout, act, _st()), "proj_maxpool_bwd")
-            extra = list(hx.wgrad(x2, d16, Cout, Cin))
+            extra = list(hx.wgrad(x16, d16, Cout, Cin))
+            del x16
             del d16
         elif r_full is not None:
             d_rf = torch.empty(M, Cout, dtype=torch.float32, device=dev)

@@ -68,7 +68,7 @@ __device__ __forceinline__ void sp_slab_mfma(const char* fa, const char* fb, con
 template <bool IDX, int NK>                        // NK = Cin / 96
 __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 ? 2 : 1)) void proj_maxpool_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    uint32_t* __restrict__ idx, int H, int W, int Ho, int Wo, int Cout, int nty, int ntx) {
+    uint32_t* __restrict__ idx, bf16_t* __restrict__ x16, int H, int W, int Ho, int Wo, int Cout, int nty, int ntx) {
     constexpr int Cin = NK * SP_BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                        // NK slabs [128][96]
@@ -98,13 +98,20 @@ __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 ? 2 : 1)) void proj_max
         int yi = 2 * yo0 - 1 + ly, xi = 2 * xo0 - 1 + lx;
         yi = yi < 0 ? 0 : (yi >= H ? H - 1 : yi);
         xi = xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
-        const float* xp = x + (uint32_t)(((bt * H + yi) * W + xi) * Cin + cch);
+        const uint32_t xo_ = (uint32_t)(((bt * H + yi) * W + xi) * Cin + cch);
+        const float* xp = x + xo_;
         uint4 v[NK];
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) v[kt] = sp_pack8(xp + kt * SP_BK);
         if (s_on) {
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) *reinterpret_cast<uint4*>(sA + kt * (SP_ROWS * SP_ROWB) + s_lds + i * 16 * SP_ROWB) = v[kt];
+            // training: the rounded rows leave once more as the 16-bit operand of the weight-gradient GEMM -- every token from the patch
+            // that holds it in its interior (rows 1..8, columns 1..12 of the 9 x 13 halo grid)
+            if (IDX && x16 && ly >= 1 && lx >= 1 && 2 * yo0 - 1 + ly < H && 2 * xo0 - 1 + lx < W && srow + 16 * i < SP_TY * SP_TX) {
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) *reinterpret_cast<uint4*>(x16 + xo_ + kt * SP_BK) = v[kt];
+            }
         }
     }
     const bf16_t* w_ptr = w + (int64_t)srow * Cin + cch;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 ? 2 : 1)) void proj_max
 #undef SF_WSTORE
 }
 
-extern "C" int mvit_proj_maxpool_fwd(const float* x, const void* w, const float* bias, float* y, void* idx, int B, int T, int H,
+extern "C" int mvit_proj_maxpool_fwd(const float* x, const void* w, const float* bias, float* y, void* idx, void* x16, int B, int T, int H,
                                      int W, int Cin, int Cout, int act_dtype, void* stream) {
     if (!x || !w || !y || B <= 0 || T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EUNSUPPORTED;            // the exact-fp32 path keeps its two separate calls
@@ -217,7 +224,7 @@ extern "C" int mvit_proj_maxpool_fwd(const float* x, const void* w, const float*
                 attr_done = true; \
             } \
         } \
-        hipLaunchKernelGGL((proj_maxpool_kernel<IDX_, NK_>), dim3((unsigned)nwg), dim3(256), smem, st, x, (const bf16_t*)w, bias, y, (uint32_t*)idx, H, W, \
+        hipLaunchKernelGGL((proj_maxpool_kernel<IDX_, NK_>), dim3((unsigned)nwg), dim3(256), smem, st, x, (const bf16_t*)w, bias, y, (uint32_t*)idx, (bf16_t*)x16, H, W, \
                            Ho, Wo, Cout, nty, ntx); }
 #define SF_GO2(NK_) { if (idx) SF_GO(true, NK_) else SF_GO(false, NK_) }
     if (Cin == 96) SF_GO2(1)

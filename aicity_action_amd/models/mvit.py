@@ -446,7 +446,7 @@ class MViT(nn.Module):
         if _skip_fused(g, act):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(r), _hip.ptr(self._w(blk.proj_max_pool.weight, act)),
-                                               _hip.ptr(blk.proj_max_pool.bias), _hip.ptr(rp), None, B, T, H, W, Cin, Cout, act, st),
+                                               _hip.ptr(blk.proj_max_pool.bias), _hip.ptr(rp), None, None, B, T, H, W, Cin, Cout, act, st),
                        "proj_maxpool")
             r = rp
         elif g.expand:

@@ -224,14 +224,15 @@ int mvit_maxpool_skip_bwd_idx(const void* idx, const float* dy, float* dx, int B
 
 /* The widening skip path of a stage-transition block in one pass (slowfast/models/attention.py:424-432: x = proj(x) then
  * attention_pool(x, pool_skip), MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1)):
- *   fwd: y[B*T*Ho*Wo][Cout] = maxpool(x[B*T*H*W][Cin] . w[Cout][Cin]^T + bias); idx (may be NULL) = mvit_maxpool_skip_fwd_idx's bytes.
+ *   fwd: y[B*T*Ho*Wo][Cout] = maxpool(x[B*T*H*W][Cin] . w[Cout][Cin]^T + bias); idx (may be NULL) = mvit_maxpool_skip_fwd_idx's bytes;
+ *        x16 (may be NULL; written only together with idx) = x rounded to the act type [B*T*H*W][Cin], the operand of the weight gradient.
  *   bwd: dx[B*T*H*W][Cin] = g . w with g = mvit_maxpool_skip_bwd_idx(idx, dy) built on chip; wt = w^T [Cin][Cout] act-typed;
  *        d16 (may be NULL) receives g [B*T*H*W][Cout] in the act type, the dy operand of the weight-gradient GEMM.
  * The widened full-resolution tensor never reaches HBM; results are bit-identical to mvit_linear_fwd (fp32 in/out) followed by
  * mvit_maxpool_skip_fwd[_idx], resp. mvit_maxpool_skip_bwd_idx followed by mvit_linear_fwd.  act_dtype MVIT_BF16 only (the exact
  * path keeps the separate calls); Cin, Cout multiples of 96; MVIT_EUNSUPPORTED otherwise. */
-int mvit_proj_maxpool_fwd(const float* x, const void* w, const float* bias, float* y, void* idx, int B, int T, int H, int W, int Cin,
-                          int Cout, int act_dtype, void* stream);
+int mvit_proj_maxpool_fwd(const float* x, const void* w, const float* bias, float* y, void* idx, void* x16, int B, int T, int H, int W,
+                          int Cin, int Cout, int act_dtype, void* stream);
 int mvit_proj_maxpool_bwd(const void* idx, const float* dy, const void* wt, float* dx, void* d16, int B, int T, int H, int W, int Cin,
                           int Cout, int act_dtype, void* stream);
 

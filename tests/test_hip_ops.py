@@ -346,12 +346,14 @@ def test_proj_maxpool_fused_skip_path(hip_lib, B, T, H, W, Cin, Cout):
     _hip.check(hip_lib.mvit_maxpool_skip_fwd_idx(_hip.ptr(full), _hip.ptr(y0), _hip.ptr(i0), B, T, H, W, Cout, _st()))
     y1 = torch.full((B, Lo, Cout), float("nan"), device=DEV)
     i1 = torch.full((B, Lo, Cout), 255, dtype=torch.uint8, device=DEV)
-    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y1), _hip.ptr(i1), B, T, H, W, Cin, Cout,
-                                             _hip.BF16, _st()))
+    x16 = torch.full((M, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y1), _hip.ptr(i1), _hip.ptr(x16), B, T, H, W,
+                                             Cin, Cout, _hip.BF16, _st()))
     assert torch.equal(y1, y0) and torch.equal(i1, i0)
-    y2 = torch.full((B, Lo, Cout), float("nan"), device=DEV)        # inference form: no index output
-    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y2), None, B, T, H, W, Cin, Cout, _hip.BF16,
-                                             _st()))
+    assert torch.equal(x16, xd.reshape(M, Cin).to(torch.bfloat16))             # every token exactly once, rounded like the GEMM operand
+    y2 = torch.full((B, Lo, Cout), float("nan"), device=DEV)        # inference form: no index output, no 16-bit copy
+    _hip.check(hip_lib.mvit_proj_maxpool_fwd(_hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(y2), None, None, B, T, H, W, Cin, Cout,
+                                             _hip.BF16, _st()))
     assert torch.equal(y2, y0)
     ref = F.linear(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias)
     ref = F.max_pool3d(ref.reshape(B, T, H, W, Cout).permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1))

@@ -158,6 +158,7 @@ def main():
         dy = torch.randn(Mo, Cout, device=dev)
         dx = torch.empty(M, Cin, device=dev)
         d16 = torch.empty(M, Cout, device=dev, dtype=torch.bfloat16)
+        x16 = torch.empty(M, Cin, device=dev, dtype=torch.bfloat16)
 
         def unfused_fwd():
             _hip.check(L.mvit_linear_fwd(_hip.ptr(x), _hip.F32, Cin, _hip.ptr(w), _hip.ptr(bias), None, Cout, None, 0, _hip.ptr(full), _hip.F32, Cout, M,
@@ -165,7 +166,7 @@ def main():
             _hip.check(L.mvit_maxpool_skip_fwd_idx(_hip.ptr(full), _hip.ptr(y), _hip.ptr(idx), B, T, H, W, Cout, st))
 
         def fused_fwd():
-            _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(y), _hip.ptr(idx), B, T, H, W, Cin, Cout, _hip.BF16, st))
+            _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(x), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(y), _hip.ptr(idx), _hip.ptr(x16), B, T, H, W, Cin, Cout, _hip.BF16, st))
 
         def unfused_bwd():
             _hip.check(L.mvit_maxpool_skip_bwd_idx(_hip.ptr(idx), _hip.ptr(dy), _hip.ptr(full), B, T, H, W, Cout, st))
