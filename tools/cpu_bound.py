@@ -50,6 +50,16 @@ for _ in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+# pure host cost: ONE step enqueued into an empty queue (the back-to-back figure above includes waiting for queue slots once the
+# launch queue is full, i.e. it converges to the GPU time)
+single = []
+for _ in range(8):
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    step()
+    single.append(time.perf_counter() - a)
+    torch.cuda.synchronize()
+print("%s streams=%d: host enqueue of one step into an empty queue: median %.2f ms (min %.2f)" % (mode, streams, sorted(single)[len(single) // 2] * 1e3, min(single) * 1e3))
 if mode == "train":
     print("optimizer chunk-table builds so far:", getattr(opt, "table_builds", 0))
 print("%s streams=%d: host enqueue %.2f ms/step, completed %.2f ms/step (GPU-bound if enqueue << completed)" % (
