@@ -101,10 +101,11 @@ def test_default_inference_arithmetic_meets_the_gate(name):
     load_synth_weights(model, meta["weight_seed"])
     clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
     with torch.no_grad():
-        assert model.precision == "fp16"
+        prec = model.precision
+        assert prec == "fp16"
         probs, logits = model._forward_hip(clip, return_logits=True)
     dl = np.abs(logits.float().cpu().numpy() - z["logits"]).max()
-    print("[%s default eval arithmetic = %s] logits err %.2e" % (name, model.precision, dl))
+    print("[%s default eval arithmetic = %s] logits err %.2e" % (name, prec, dl))
     assert dl <= 1e-3
     assert model.train().precision == "bf16"
 

@@ -1,22 +1,22 @@
 #!/usr/bin/env python3
 """Generates the per-slot softmax statements of csrc/attention_w64.hip (between the GENERATED markers).
 
-A pair of scores goes through four ops -- A: t = s*c - m*c (v_pk_fma, 8 issue cycles), B0 / B1: the two v_exp (8 each), C: row sum +
-pack (v_pk_add 8 + v_cvt_pk 4).  The 16 pairs of a query block are software-pipelined (A of pair r beside the exps of pair r-1 and the
-C of pair r-2: no op follows the op it depends on) and the resulting op stream is cut into the MFMA slots of a phase by issue cost.
+A pair of scores goes through three ops -- B0 / B1: the two v_exp_f32 (8 issue cycles each), C: row sums + pack (two v_add 8 + v_cvt_pk 4).
+The 16 pairs of a query block are software-pipelined (no op follows the op it depends on) and the op stream is cut into the MFMA
+slots of a phase by issue cost.
 usage: tools/gen_w64_slots.py  (rewrites the file in place)"""
 import os, re
-COST = {"A": 8, "B0": 8, "B1": 8, "C": 12}
+COST = {"B0": 8, "B1": 8, "C": 12}
 
 def stream(pairs):
-    """pairs: list of (query block, pair index) in execution order -> software-pipelined op list [(op, block, pair)]"""
+    """pairs: list of (query block, pair index, position) in execution order -> software-pipelined op list [(op, block, pair, position)].
+    The scores come out of the MFMA chain already relative to the row's reference point and in log2 units (Q is pre-scaled, the
+    accumulators start at -reference), so a pair is two exponentials and one sum + pack; C of pair r-1 sits three ops behind its B1."""
     ops, n = [], len(pairs)
-    for r in range(n + 2):
-        # order inside a round: every op sits three ops behind the one it depends on
-        if 0 <= r - 1 < n: ops.append(("B0",) + pairs[r - 1])
-        if r < n: ops.append(("A",) + pairs[r])
-        if 0 <= r - 2 < n: ops.append(("C",) + pairs[r - 2])
-        if 0 <= r - 1 < n: ops.append(("B1",) + pairs[r - 1])
+    for r in range(n + 1):
+        if r < n: ops.append(("B0",) + pairs[r])
+        if r < n: ops.append(("B1",) + pairs[r])
+        if 0 <= r - 1 < n: ops.append(("C",) + pairs[r - 1])
     return ops
 
 def cut(ops, slots):
@@ -29,13 +29,12 @@ def cut(ops, slots):
     return out
 
 def emit(ops, s, pf, ps):
-    """in-flight state is indexed by position in the pair list modulo 3 (three pairs in flight)"""
+    """in-flight state is indexed by position in the pair list modulo 2 (two pairs in flight)"""
     t = []
     for o, j, e, k in ops:
-        E, K, J = "IC<%d>{}" % e, "IC<%d>{}" % (k % 3), "J%d{}" % j
-        if o == "A": t.append("ex_a(%s, %s, %s, %s, mc2);" % (s, J, E, K))
-        elif o == "B0": t.append("ex_b0(%s);" % K)
-        elif o == "B1": t.append("ex_b1(%s);" % K)
+        E, K, J = "IC<%d>{}" % e, "IC<%d>{}" % (k % 2), "J%d{}" % j
+        if o == "B0": t.append("ex_b0(%s, %s, %s, %s);" % (s, J, E, K))
+        elif o == "B1": t.append("ex_b1(%s, %s, %s, %s);" % (s, J, E, K))
         else: t.append("ex_c(%s, %s, %s, %s, %s[%d]);" % (pf, J, E, K, ps, j))
     return " ".join(t)
 
