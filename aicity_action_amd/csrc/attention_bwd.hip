@@ -242,8 +242,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     // consume the register operands once: their vmcnt wait is paid here, not inside the loop
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+    // Q is scaled by scale * log2(e) once (and rounded to the 16-bit type again) and every score accumulator starts at -lse: the scores
+    // leave the MFMA chain as the exponent itself (P = exp2(S), no multiply-add per element); -delta likewise rides on the dP chain
+    {
+        auto scl = [&](short lo, short hi) { return pack_bf16x2(bf16_to_f32((bf16_t)lo) * scale_log2e, bf16_to_f32((bf16_t)hi) * scale_log2e); };
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const uint4 u = make_uint4(scl(qf[ks][0], qf[ks][1]), scl(qf[ks][2], qf[ks][3]), scl(qf[ks][4], qf[ks][5]), scl(qf[ks][6], qf[ks][7]));
+            qf[ks] = *reinterpret_cast<const bf16x8*>(&u);
+        }
+    }
     asm volatile("" : "+v"(lse), "+v"(dlt));
-    const float ndlt = -dlt;
+    const float ndlt = -dlt, nlse = -lse;
 
     // K / V row fragment of k-step ks: row r, 16-B chunk (2ks + h + rot(r)) mod 12 with rot <= 3: k-steps 0..3 never wrap (immediate
     // offsets from one lane address), k-steps 4 and 5 each get their own
@@ -301,14 +311,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    s[kb][i] = key < Lk ? 0.f : -INFINITY;
+                    s[kb][i] = key < Lk ? nlse : -INFINITY;
                     dp[kb][i] = ndlt;
                 }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = ndlt; }       // dP^T - delta comes out of the MFMA chain
+                for (int i = 0; i < 16; ++i) { s[kb][i] = nlse; dp[kb][i] = ndlt; }       // S c - lse and dP^T - delta come out of the MFMA chains
         }
         // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order)
         bf16x8 kf[3], vf[3];
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #define DQ_RD(SL, A, OFF, KB) { kf[SL] = b_rd128<OFF + (KB) * 32 * B_ROWB>(A); vf[SL] = b_rd128<OFF + B_T * B_ROWB + (KB) * 32 * B_ROWB>(A); }
 #define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[SL]), "+v"(vf[SL]) : "n"(N))
 #define DQ_MM(SL, KS, KB) { s[KB] = mfma16(kf[SL], qf[KS], s[KB]); dp[KB] = mfma16(vf[SL], dof[KS], dp[KB]); }
-#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(fmaf(s[KB][I], scale_log2e, -lse)); dsv[KB][I] = p_ * dp[KB][I]; }
+#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(s[KB][I]); dsv[KB][I] = p_ * dp[KB][I]; }
 #define DQ_SB __builtin_amdgcn_sched_barrier(0);
 #define TRQ(A, S16) \
         A[0] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[0] + so); A[1] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[0] + so); \
