@@ -601,7 +601,7 @@ def _forward_train_one(model, clip, hx, dp_all, mask):
 def forward_train(model, clip):
     """Forward in training mode (drop-path + head dropout active when model.training); returns raw logits.
     Builds the autograd graph when grad mode is on.  With HIP.TRAIN_STREAMS > 1 (default 1: measured slower at B=8 @448, 78.7
-    vs 72.4 ms -- twice the launches and half-size weight-gradient GEMMs outweigh the filled tails) and >= 2 clips per stream the batch
+    vs 72.4 ms in round 1 and 57.5 vs 49.2 ms in round 3 (profiles/r3_train_streams.txt) -- twice the launches and half-size weight-gradient GEMMs outweigh the filled tails) and >= 2 clips per stream the batch
     runs as sub-batches on side streams (forward and, through autograd's stream bookkeeping, backward): the kernels of one
     sub-batch fill the last partial wave of workgroups of the other; parameter gradients of the chains are summed by autograd."""
     hx = _Ctx(model)

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"],
                     help="default: HIP.PRECISION auto = bf16 for the train modes, fp16 (the arithmetic that meets the 1e-3 logit gate) for fwd / window")
     ap.add_argument("--streams", type=int, default=3, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
+    ap.add_argument("--train-streams", type=int, default=1, help="training: sub-batches on separate HIP streams (cfg HIP.TRAIN_STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward-record", action="store_true", help="train mode: skip the extra eval-forward timing")
@@ -89,7 +90,8 @@ def main():
             dist.init_process_group(backend)
 
     yaml = "MVITV2_FULL_B_16x4_CONV_448.yaml" if args.crop == 448 else "MVITV2_FULL_B_16x4_CONV.yaml"
-    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision, "HIP.STREAMS", args.streams])
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", yaml), ["NUM_GPUS", 1, "HIP.PRECISION", args.precision, "HIP.STREAMS", args.streams,
+                                                                      "HIP.TRAIN_STREAMS", args.train_streams])
     mv = copy.deepcopy(cfg.MVIT.to_dict())
     train = args.mode in ("train", "loop")
     manual_ddp = False
