@@ -38,18 +38,36 @@ class SlidingWindowClassifier(object):
         self.frame_length, self.proposal_length, self.proposal_stride = frame_length, proposal_length, proposal_stride
         self.frame_size, self.batch_size, self.mean, self.std = frame_size, batch_size, mean, std
 
-    def preprocess(self, frames_u8, windows):
-        """frames_u8: uint8 [N,H,W,3] on the GPU; windows: list of (t0,t1) -> fp32 [len(windows),3,T,S,S]."""
+    def window_frame_indices(self, windows, num_frames, device):
+        """int32 [len(windows), T] on the device: the frames each window samples (module_wrapper.py:304-370)."""
+        idx = torch.stack([frame_idxs_uniform(t0, t1, self.frame_length, num_frames) for t0, t1 in windows]).to(torch.int32)
+        return idx.to(device)
+
+    def preprocess(self, frames_u8, windows, idx=None):
+        """frames_u8: uint8 [N,H,W,3] on the GPU; windows: list of (t0,t1) -> fp32 [len(windows),3,T,S,S].
+        idx: the windows' rows of window_frame_indices, already on the device (run() uploads the whole view's table once: an upload
+        per batch is a stream-ordered blocking copy, i.e. the host would wait for the previous batch's forward before it could
+        enqueue the next one)."""
         N, H, W, C = frames_u8.shape
         assert frames_u8.dtype == torch.uint8 and C == 3 and frames_u8.is_cuda and frames_u8.is_contiguous()
-        idx = torch.stack([frame_idxs_uniform(t0, t1, self.frame_length, N) for t0, t1 in windows]).to(torch.int32)
-        idx = idx.to(frames_u8.device)
+        idx = self.window_frame_indices(windows, N, frames_u8.device) if idx is None else idx
         S = self.frame_size
         out = torch.empty(len(windows), 3, self.frame_length, S, S, dtype=torch.float32, device=frames_u8.device)
         _hip.check(_hip.lib().mvit_window_preprocess(_hip.ptr(frames_u8), _hip.ptr(idx), _hip.ptr(out), H, W, S, len(windows),
                                                      self.frame_length, self.mean, self.std,
                                                      torch.cuda.current_stream().cuda_stream), "window_preprocess")
         return out
+
+    def batch_bounds(self, n):
+        """[(i0, i1)] over n windows: batches of batch_size as the reference's DataLoader makes them (module_wrapper.py:384-397),
+        except that a ragged tail of at most batch_size // 4 windows rides with the batch before it (57 windows at batch 8 ->
+        6 x 8 + 9 instead of 7 x 8 + 1: a one-clip forward costs a third of an eight-clip one).  A window's scores do not depend on
+        the batch it is in (every kernel of the forward is row- / clip-local)."""
+        bs = self.batch_size
+        cuts = list(range(0, n, bs)) + [n]
+        if len(cuts) > 2 and 0 < cuts[-1] - cuts[-2] <= bs // 4:
+            del cuts[-2]
+        return list(zip(cuts[:-1], cuts[1:]))
 
     @torch.no_grad()
     def run(self, frames_u8, shard=True):
@@ -61,9 +79,10 @@ class SlidingWindowClassifier(object):
         world = du.get_world_size() if shard else 1
         mine = du.shard_indices(len(windows), pad=True) if world > 1 else list(range(len(windows)))
         probs = []
-        for i in range(0, len(mine), self.batch_size):
-            chunk = [windows[j] for j in mine[i:i + self.batch_size]]
-            clips = self.preprocess(frames_u8, chunk)
+        idx_all = self.window_frame_indices([windows[j] for j in mine], N, frames_u8.device)
+        for i0, i1 in self.batch_bounds(len(mine)):
+            chunk = [windows[j] for j in mine[i0:i1]]
+            clips = self.preprocess(frames_u8, chunk, idx_all[i0:i1])
             probs.append(self.model([clips]).float())
         probs = torch.cat(probs, 0)
         if world > 1:

@@ -86,7 +86,8 @@ def test_sliding_window_real_size_one_view():
     assert len(res) == 57 and [(r[0], r[1]) for r in res] == wins and res[-1][1] == 960
     for t0, t1, p in res:
         assert p.dtype == np.float32 and p.shape == (18,) and abs(float(p.sum()) - 1.0) < 1e-4 and np.isfinite(p).all()
-    for k in (0, 23, 56):                       # batch positions 0, 7 and the ragged last batch (57 = 7 x 8 + 1)
+    assert [b - a for a, b in swc.batch_bounds(57)] == [8] * 6 + [9]
+    for k in (0, 23, 56):                       # batch positions 0, 7 and the last window, which rides with the batch before it (6 x 8 + 9)
         t0, t1, p = res[k]
         clip = swc.preprocess(frames, [(t0, t1)])
         with torch.no_grad():
