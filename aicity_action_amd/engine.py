@@ -263,7 +263,7 @@ def train_epoch(train_loader, model, optimizer, scaler, train_meter, cur_epoch, 
             continue
         preds = model(inputs)
         loss = _loss(cfg, preds, labels)
-        optimizer.zero_grad(set_to_none=True)      # (train_net.py:228; dropping the buffers instead of 350 zero-fill + 350 accumulate launches)
+        optimizer.zero_grad()               # (train_net.py:228; HipAdamW drops the buffers: no 350 zero-fill + 350 accumulate launches)
         if scaler is not None and scaler.is_enabled():
             scaler.scale(loss).backward()
             scaler.step(optimizer)          # unscale + inf check + clip + AdamW fused in the optimizer step

@@ -124,7 +124,7 @@ class DeviceScalarQueue(object):
             self._alloc()
         if len(self._pending) == self.depth:         # the slot about to be reused: its copy must have landed
             self._retire(wait=True, count=1)
-        slot = self._slots[self._next]
+        slot = self._slots[self._next][:t.numel()]   # (rows may be shorter than the slot: the ragged last batch of a test loop)
         self._next = (self._next + 1) % self.depth
         slot.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
@@ -348,15 +348,40 @@ class TestMeter(_IterClock):
         self.video_labels = torch.zeros((num_videos,)).long()
         self.clip_count = torch.zeros((num_videos,)).long()
         self.stats = {}
+        self._queue = None
 
     def reset(self):
+        self.flush()
         for t in (self.video_preds, self.video_labels, self.clip_count):
             t.zero_()
 
     def update_stats(self, preds, labels, clip_ids):
-        preds = preds.detach().float().cpu()
-        labels = labels.detach().cpu().long()
-        vid = torch.div(clip_ids.detach().cpu().long(), self.num_clips, rounding_mode="floor")
+        """The reference moves the three tensors to the host here (meters.py:354-390 ``.cpu()``), a sync per iteration that lets the
+        GPU run dry between forwards.  Device tensors travel through a DeviceScalarQueue instead (one packed non-blocking copy;
+        absorbed into ``video_preds`` at most two iterations later, all of them by ``finalize_metrics`` / ``flush``)."""
+        if not preds.is_cuda:
+            return self._apply(preds.detach().float(), labels.detach().long(), clip_ids.detach().long())
+        B, C = preds.shape
+        row = torch.cat([preds.detach().reshape(-1).double(), labels.detach().reshape(-1).double(), clip_ids.detach().reshape(-1).double()])
+        if self._queue is None or self._queue.width < row.numel():
+            self.flush()
+            self._queue = DeviceScalarQueue(row.numel(), depth=2)
+        self._queue.put(row, (B, C))
+        self._absorb(wait=False)
+
+    def _absorb(self, wait):
+        if self._queue is None:
+            return
+        for row, (B, C) in self._queue.ready(wait=wait):
+            row = torch.from_numpy(row)
+            self._apply(row[:B * C].view(B, C).float(), row[B * C:B * C + B].long(), row[B * C + B:].long())
+
+    def flush(self):
+        """Waits for every queued batch and folds it into ``video_preds`` / ``video_labels`` / ``clip_count``."""
+        self._absorb(wait=True)
+
+    def _apply(self, preds, labels, clip_ids):
+        vid = torch.div(clip_ids, self.num_clips, rounding_mode="floor")
         seen = self.video_labels[vid] > 0                                   # a label already on file must not change
         assert torch.equal(self.video_labels[vid][seen], labels[seen]), "clips of one video disagree on its label"
         self.video_labels[vid] = labels
@@ -374,6 +399,7 @@ class TestMeter(_IterClock):
 
     def finalize_metrics(self, ks=(1, 5)):
         from .engine import topks_correct
+        self.flush()
         short = [(i, int(c)) for i, c in enumerate(self.clip_count.tolist()) if c != self.num_clips]
         if short:
             logger.warning("clip count {} != num clips {}".format(", ".join("{}: {}".format(i, c) for i, c in short), self.num_clips))

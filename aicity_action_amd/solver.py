@@ -83,7 +83,9 @@ class HipAdamW(object):
     def set_lr(self, lr):
         self.lr = float(lr)
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad (default set_to_none=True as in torch >= 2.0: the gradient buffers are dropped, the next
+        backward writes fresh ones instead of accumulating into zero-filled ones)."""
         for grp in self.groups:
             for p in grp["params"]:
                 if p.grad is not None:
