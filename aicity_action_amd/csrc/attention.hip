@@ -771,6 +771,13 @@ int attn_fwd_w64_prepare();
 int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads, int Lq, int Lk,
                         float scale_log2e, int add_q, hipStream_t st);
 
+// True when the 16-bit forward of this shape runs in the 64-query kernel, whose scores (and saved lse) are those of the PRE-SCALED
+// 16-bit queries round16(q * scale * log2e); the backward (attention_bwd.hip) recomputes its scores from the same values.
+bool attn_fwd_prescales_q(int Lq, int Lk) {
+    static const bool w64_env = !(getenv("MVIT_ATT_W64") && atoi(getenv("MVIT_ATT_W64")) == 0);
+    return w64_env && Lk >= 64 && Lq >= 128;
+}
+
 extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
                                   int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return MVIT_EINVAL;
@@ -779,8 +786,7 @@ extern "C" int mvit_attention_fwd(const void* q, const void* k, const void* v, v
     if (act_dtype == MVIT_BF16) {
         // default: 64 queries per wave, one wave per SIMD (attention_w64.hip; +11 % on the model's shapes); MVIT_ATT_W64=0 selects the
         // 32-query kernels below, which also serve short sequences
-        static const bool w64_env = !(getenv("MVIT_ATT_W64") && atoi(getenv("MVIT_ATT_W64")) == 0);
-        if (w64_env && Lk >= 64 && Lq >= 128) {
+        if (attn_fwd_prescales_q(Lq, Lk)) {
             static bool wattr_done = false;
             if (!wattr_done) { const int rc = attn_fwd_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
             const int rc = attn_fwd_w64_launch(q, k, v, out, lse, B, heads, Lq, Lk, scale * 1.44269504088896340736f, add_q, st);

@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const T* __restrict
 // 192 threads x 16 B = 3 KiB contiguous per load; the 4-lanes-per-row kernel above touched sixteen 64-byte pieces of sixteen rows
 // per wave-instruction and ran at 2.7 TB/s); the twelve chunk sums of a (b, q, head) meet in LDS.  192 = 16 x 12 threads and
 // every row is a multiple of twelve chunks, so a group never straddles a workgroup or a row.
+// Qs (optional): the pre-scaled 16-bit queries round16(q * scale_log2e) -- bit for bit what the 64-query forward kernel and the dQ pass
+// build in registers -- for the dK/dV pass, whose query tiles go from memory to LDS without passing through registers.
 __global__ __launch_bounds__(192) void attn_bwd_delta_flat_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                                   const bf16_t* __restrict__ Q, float* __restrict__ delta,
-                                                                  int heads, int Lq, int64_t nchunks, int add_q) {
+                                                                  int heads, int Lq, int64_t nchunks, int add_q,
+                                                                  bf16_t* __restrict__ Qs, float scale_log2e) {
     __shared__ float part[192];
     const int cpr = 12 * heads;                                    // chunks per (b, q) row
     for (int64_t c0 = (int64_t)blockIdx.x * 192; c0 < nchunks; c0 += (int64_t)gridDim.x * 192) {
@@ -107,11 +110,17 @@ __global__ __launch_bounds__(192) void attn_bwd_delta_flat_kernel(const bf16_t* 
             float4 d0, d1, o0, o1;
             load8(dO + c * 8, d0, d1);
             load8(O + c * 8, o0, o1);
-            if (add_q) {
+            if (add_q || Qs) {
                 float4 q0, q1;
                 load8(Q + it * 96 + 8 * k, q0, q1);
-                o0.x -= q0.x; o0.y -= q0.y; o0.z -= q0.z; o0.w -= q0.w;
-                o1.x -= q1.x; o1.y -= q1.y; o1.z -= q1.z; o1.w -= q1.w;
+                if (Qs)
+                    *reinterpret_cast<uint4*>(Qs + it * 96 + 8 * k) =
+                        make_uint4(pack_bf16x2(q0.x * scale_log2e, q0.y * scale_log2e), pack_bf16x2(q0.z * scale_log2e, q0.w * scale_log2e),
+                                   pack_bf16x2(q1.x * scale_log2e, q1.y * scale_log2e), pack_bf16x2(q1.z * scale_log2e, q1.w * scale_log2e));
+                if (add_q) {
+                    o0.x -= q0.x; o0.y -= q0.y; o0.z -= q0.z; o0.w -= q0.w;
+                    o1.x -= q1.x; o1.y -= q1.y; o1.z -= q1.z; o1.w -= q1.w;
+                }
             }
             s = (d0.x * o0.x + d0.y * o0.y) + (d0.z * o0.z + d0.w * o0.w) + (d1.x * o1.x + d1.y * o1.y) + (d1.z * o1.z + d1.w * o1.w);
         }
@@ -785,10 +794,16 @@ static int dkv_splits(int B, int heads, int Lq, int Lk) {
     return (int)(z < 1 ? 1 : z);
 }
 
-// delta [B*heads*Lq] + (split path) fp32 dK, dV partial slabs [2][splits][B*heads*Lk*96]
-extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk) {
+bool attn_fwd_prescales_q(int Lq, int Lk);      // attention.hip
+
+// delta [B*heads*Lq] + (split path) fp32 dK, dV partial slabs [2][splits][B*heads*Lk*96] + the pre-scaled 16-bit queries [B*heads*Lq*96]
+static int64_t ws_qs_offset_floats(int B, int heads, int Lq, int Lk) {
     const int nz = dkv_splits(B, heads, Lq, Lk);
-    return ((int64_t)B * heads * Lq + (nz > 1 ? 2ll * nz : 0ll) * B * heads * Lk * 96) * (int64_t)sizeof(float);
+    const int64_t n = (int64_t)B * heads * Lq + (nz > 1 ? 2ll * nz : 0ll) * B * heads * Lk * 96;
+    return (n + 3) & ~3ll;                       // 16-byte aligned
+}
+extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk) {
+    return ws_qs_offset_floats(B, heads, Lq, Lk) * (int64_t)sizeof(float) + (int64_t)B * heads * Lq * 96 * 2;
 }
 
 // the 64-query form of pass A by itself (tests, tools): delta = mvit_attention_bwd's workspace head (fp32 [B*heads*Lq])
@@ -819,12 +834,19 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
     const float sl2 = scale * 1.44269504088896340736f;
     if (act_dtype == MVIT_BF16) {
         static const bool flat_delta = getenv("MVIT_ATT_DELTA_ROWS") == nullptr;
+        // When the forward ran in the 64-query kernel its scores -- and the saved lse -- are those of round16(q * scale * log2e).  The dQ
+        // pass builds the same values in registers; the dK/dV pass streams its query tiles straight into LDS, so the delta kernel
+        // (which reads q anyway) leaves it a pre-scaled copy: all three kernels then exponentiate bit-identical scores.  (With the
+        // dK/dV pass on the unscaled q, rows with a dominant key -- scores of 20 ... 60 in the exp2 domain -- saw P off by
+        // 2^(s * 2^-9): dV errors of 1-2 % instead of 0.3 %, tools/probes/attn_peaked.py.)
+        bf16_t* qs = (flat_delta && attn_fwd_prescales_q(Lq, Lk))
+                         ? reinterpret_cast<bf16_t*>(workspace + ws_qs_offset_floats(B, heads, Lq, Lk)) : nullptr;
         if (flat_delta) {
             const int64_t nchunks = rows * 12;
             int64_t fb = (nchunks + 191) / 192;
             if (fb > 8192) fb = 8192;
             hipLaunchKernelGGL(attn_bwd_delta_flat_kernel, dim3((unsigned)fb), dim3(192), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                               (const bf16_t*)q, workspace, heads, Lq, nchunks, add_q);
+                               (const bf16_t*)q, workspace, heads, Lq, nchunks, add_q, qs, sl2);
         } else {
             hipLaunchKernelGGL((attn_bwd_delta_kernel<bf16_t>), dim3((unsigned)dblocks), dim3(256), 0, st, (const bf16_t*)dout,
                                (const bf16_t*)out, (const bf16_t*)q, workspace, B, heads, Lq, add_q);
@@ -874,13 +896,17 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             dkv_attr_done = true;
         }
         const int nz = dkv_splits(B, heads, Lq, Lk);
+        // pre-scaled queries: the scores come out of the MFMA in the exp2 domain (multiplier 1), and dK = scale * dS^T q =
+        // (scale / (scale log2e)) * dS^T qs
+        const bf16_t* q_kv = qs ? qs : (const bf16_t*)q;
+        const float sl2_kv = qs ? 1.0f : sl2, scale_kv = qs ? scale / sl2 : scale;
         if (nz > 1) {
             float* dkf = workspace + rows;
             const int64_t nkv = (int64_t)B * heads * Lk * 96;
             float* dvf = dkf + (int64_t)nz * nkv;
             dim3 gk((Lk + 127) / 128, B * heads, nz);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), BK_LDS, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale, sl2);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
+                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv);
             MVIT_LAUNCH_CHECK();
             int64_t cb = (nkv / 4 + 255) / 256;
             if (cb > 4096) cb = 4096;
@@ -888,8 +914,8 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             MVIT_LAUNCH_CHECK();
         } else {
             dim3 gk((Lk + 127) / 128, B * heads);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), BK_LDS, skv, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale, sl2);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
+                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale_kv, sl2_kv);
             MVIT_LAUNCH_CHECK();
         }
         if (skv != st && !side_join(ss, st)) return MVIT_ELAUNCH;

@@ -228,6 +228,40 @@ def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
     _close(db2, b.grad, tol)
 
 
+@pytest.mark.parametrize("c", [0.0, 1.0, 3.0])
+def test_attention_bwd_rows_with_a_dominant_key(hip_lib, c):
+    """Every second query has one key c * q planted (scores up to ~60 in the exp2 domain for c = 3: a trained model's peaked heads).
+    The 64-query forward kernel exponentiates the scores of the pre-scaled 16-bit queries and saves their lse; the backward must rebuild
+    its probabilities from the SAME rounded queries (dQ pass: in registers; dK/dV pass: the copy the delta kernel leaves in the
+    workspace) -- on the unscaled queries P is off by 2^(score * 2^-9) in exactly these rows and dV came out 1-2 % wrong
+    (tools/probes/attn_peaked.py).  Reference: fp32 autograd on the same 16-bit operands (attention.py:267-279)."""
+    B, h, Lq, Lk = 1, 2, 512, 1568
+    scale = 96 ** -0.5
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (torch.randn(B, h, n, 96, generator=g) for n in (Lq, Lk, Lk))
+    do = torch.randn(B, Lq, h * 96, generator=g)
+    if c:
+        for i in range(0, Lq, 2):
+            k[0, :, (37 * i) % Lk] = q[0, :, i] * c
+    q, k, v, do = (t.to(torch.bfloat16) for t in (q, k, v, do))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    o = (((qr @ kr.transpose(-2, -1)) * scale).softmax(-1) @ vr + qr).transpose(1, 2).reshape(B, Lq, h * 96)
+    o.backward(do.float())
+    qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
+    out = torch.empty(B, Lq, h * 96, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, h, Lq, device=DEV)
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk, scale, 1,
+                                          _hip.BF16, _st()))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk) // 4, device=DEV)
+    _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod), _hip.ptr(dq),
+                                          _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, 1, _hip.BF16, _st()))
+    _close(out, o.detach(), 5e-3)
+    _close(dv, vr.grad, 7e-3)            # 3.2e-3 ... 4.4e-3 measured; 1.1e-2 ... 2.4e-2 with inconsistent scores
+    _close(dq, qr.grad, 2e-2)
+    _close(dk, kr.grad, 2e-2)
+
+
 @pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(1, 1, 256, 200, 1), (1, 2, 257, 392, 0), (2, 1, 300, 1568, 1), (1, 1, 5000, 256, 1)])
 def test_attention_bwd_dq_64_query_form(hip_lib, B, h, Lq, Lk, add_q):
     """The 64-queries-per-wave form of the dQ pass (csrc/attention_bwd_w64.hip; opt-in, MVIT_ATT_DQ_W64=1) against autograd and against

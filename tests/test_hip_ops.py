@@ -312,6 +312,40 @@ def test_attention_bf16_online_softmax_rescale_is_exercised(hip_lib):
     _close(out, ref, 1e-2)
 
 
+@pytest.mark.parametrize("Lq,Lk", [(256, 448), (300, 549), (128, 64), (513, 1568 + 40)])
+def test_attention_64_query_kernel_rescale_paths_and_lse(hip_lib, Lq, Lk):
+    """csrc/attention_w64.hip (the default forward for Lk >= 64, Lq >= 128) keeps a LAGGING softmax reference per row: the output is
+    rescaled only when a row's maximum jumps by more than 2^8, smaller jumps ride on the old reference.  Keys planted late in the
+    sequence make rows take both paths (jumps of ~2^5 and ~2^40 in the exp2 domain), in the first key tile visited (the ragged one), in
+    the middle and in the last tile, for odd and even tile counts; checked: the output and the saved row statistic
+    lse = log2(sum_k exp(score)) (include/mvit_hip.h) that the backward pass starts from (attention.py:267-279)."""
+    B, h = 1, 2
+    q = _rnd(B, h, Lq, 96, seed=31)
+    k = _rnd(B, h, Lk, 96, seed=32)
+    v = _rnd(B, h, Lk, 96, seed=33)
+    nt = (Lk + 63) // 64
+    plant = [(3, Lk - 1, 3.0), (70, Lk - 5, 0.4), (5, 64 * (nt // 2) + 7, 2.5), (64, 64 * (nt // 2) + 9, 0.45), (17, 1, 3.0),
+             (127, min(Lk - 1, 64 * (nt - 1) + 2), 0.5), (Lq - 1, Lk - 2, 2.0), (Lq - 2, 0, 0.4)]
+    for qi, kj, c in plant:
+        k[0, :, kj] = q[0, :, qi] * c
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    scale = 96 ** -0.5
+    s = (q.float() @ k.float().transpose(-2, -1)) * scale
+    ref = (s.softmax(-1) @ v.float() + q.float()).transpose(1, 2).reshape(B, Lq, h * 96)
+    ref_lse = torch.logsumexp(s, -1) * 1.4426950408889634
+    out = torch.empty(B, Lq, h * 96, dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((B, h, Lq), float("nan"), dtype=torch.float32, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk, scale, 1,
+                                          _hip.BF16, _st()))
+    _close(out, ref, 1e-2)
+    # the kernel's scores are those of the pre-scaled 16-bit queries round16(q * scale * log2e) (include/mvit_hip.h): a row's statistic
+    # may sit |score| * 2^-9 away from the exact one (log2 units), on top of the 2e-3 of the diffuse rows
+    bound = 2e-3 + (s.abs().amax(-1) * 1.4426950408889634) * 2.0 ** -9
+    err = (lse.cpu() - ref_lse).abs()
+    assert bool((err <= bound).all()), "lse err %.3e (bound there %.3e)" % (err.max().item(), bound.flatten()[err.argmax()].item())
+
+
 @pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 2, 14, 14, 768), (1, 1, 5, 9, 96)])
 def test_maxpool_skip(hip_lib, B, T, H, W, C):
     x = _rnd(B, T * H * W, C, seed=22)
