@@ -287,3 +287,53 @@ def test_train_step_is_bit_reproducible(precision):
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), "gradient " + k
         assert torch.equal(outs[0][2][k], outs[1][2][k]), "parameter " + k
+
+
+@pytest.mark.parametrize("gain", [1.0, 2.5])
+def test_small_model_with_peaked_attention_against_the_oracle(gain):
+    """The goldens are taken at random initialisation, where every attention row is diffuse.  A trained model's heads are peaked, and
+    that regime is where the 16-bit attention kernels' shortcuts could bite (pre-scaled queries, lagging softmax reference, lse handed
+    to the backward).  A 4-block model at crop 128 (Lq = 2048 / 512, Lk = 128: the 64-query forward kernel and the full backward run)
+    with the LayerNorm gains of the pooled q and k multiplied by `gain` (scores x gain^2: rows with one dominant key at 2.5), forward
+    and backward in bf16 against autograd over the oracle (fp32, attention.py:222-284).  Bounds as for the golden cases: logits 3e-2,
+    gradient cosine >= 0.995, global norm within 5 %."""
+    import copy
+    import os
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvit_oracle as O
+    from aicity_action_amd.autograd import forward_train
+    from aicity_action_amd.config import load_config
+
+    opts = ["MVIT.DEPTH", 4, "MVIT.DIM_MUL", [[1, 2.0], [3, 2.0]], "MVIT.HEAD_MUL", [[1, 2.0], [3, 2.0]],
+            "MVIT.POOL_Q_STRIDE", [[1, 1, 2, 2], [3, 1, 2, 2]], "MVIT.POOL_KV_STRIDE_ADAPTIVE", [1, 4, 4], "MVIT.DROPPATH_RATE", 0.0,
+            "MODEL.DROPOUT_RATE", 0.0, "DATA.NUM_FRAMES", 4, "DATA.TRAIN_CROP_SIZE", 128, "DATA.TEST_CROP_SIZE", 128, "NUM_GPUS", 1,
+            "HIP.PRECISION", "bf16"]
+    cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"), opts)
+    mv = copy.deepcopy(cfg.MVIT.to_dict())
+    model = build_model(cfg).train()
+    load_synth_weights(model, 11)
+    with torch.no_grad():
+        for blk in model.blocks:
+            for nm in ("norm_q", "norm_k"):
+                ln = getattr(blk.attn, nm, None)
+                if ln is not None:
+                    ln.weight.mul_(gain)
+    assert all(g.lk >= 64 and g.lq >= 128 for g in model.geoms[:3]), [(g.lq, g.lk) for g in model.geoms]
+    clip = synth_clip(2, 4, 128, 21)
+    w = torch.linspace(-1.0, 1.0, 2 * cfg.MODEL.NUM_CLASSES).reshape(2, -1)
+    lg = forward_train(model, clip.cuda())
+    (lg * w.cuda()).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    _, o_lg = O.forward(sd, clip, mv, training=False, head_act=False)
+    (o_lg * w).sum().backward()
+    # how peaked block 0's attention is in the oracle: mean of the largest softmax weight per row is not exposed; the logit error
+    # and the gradient agreement are what is asserted
+    err = (lg.detach().cpu() - o_lg.detach()).abs().max().item()
+    a = torch.cat([p.grad.detach().flatten().cpu() for _, p in model.named_parameters()]).double()
+    b = torch.cat([sd[k].grad.flatten() for k, _ in model.named_parameters()]).double()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    print("[peaked attention, gain %.1f bf16] logits max|diff| %.2e  |g| %.4f (oracle %.4f)  gradient cosine %.5f" % (gain, err, a.norm(), b.norm(), cos))
+    assert err <= 3e-2 and cos >= 0.995 and abs(float(a.norm() / b.norm()) - 1.0) <= 0.05
