@@ -15,6 +15,10 @@ bool mvit_internal_linear_pp_ok(int64_t lda, int64_t M, int N, int K);
 int mvit_internal_linear_pp(int epi, const void* a, int64_t lda, const void* w, const float* bias, const void* aux, int64_t ldaux,
                             const float* row_scale, int64_t rps, void* y, void* y2, int64_t ldy, int64_t M, int N, int K, hipStream_t st);
 enum { PP_B16 = 0, PP_GELU16 = 1, PP_GELU_PRE = 2, PP_GELU_DER = 3, PP_F32 = 4, PP_F32_RES = 5, PP_F32_RES_SC = 6, PP_DG_PRE = 7, PP_DG_DER = 8 };
+// linear_k96.hip: K = 96 layers on long token streams, weights resident in LDS (epilogue codes 0..3 = PP_B16 .. PP_GELU_DER)
+bool mvit_internal_linear_k96_ok(int64_t lda, int64_t M, int N, int K);
+int mvit_internal_linear_k96(int epi, const void* a, int64_t lda, const void* w, const float* bias, void* y, void* y2, int64_t ldy, int64_t M,
+                             int N, hipStream_t st);
 // Which shapes go to it (MVIT_GEMM_PP=0 / 1 forces off / on for every shape it can take): measured per shape in profiles/r3_gemm_shapes.txt
 static inline bool use_pp(int64_t lda, int64_t M, int N, int K, int code) {
     static const char* env = getenv("MVIT_GEMM_PP");
@@ -1174,6 +1178,8 @@ extern "C" int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const vo
             if (res && (ldr & 3) == 0) code = row_scale ? PP_F32_RES_SC : PP_F32_RES;
             else if (!res && !row_scale) code = PP_F32;
         }
+        if ((code == PP_B16 || code == PP_GELU16) && (epilogue & MVIT_EPI_BIAS) && mvit_internal_linear_k96_ok(lda, M, N, K))
+            return mvit_internal_linear_k96(code, a, lda, w, bias, y, nullptr, ldy, M, N, st);
         if (code >= 0 && use_pp(lda, M, N, K, code))
             return mvit_internal_linear_pp(code, a, lda, w, (epilogue & MVIT_EPI_BIAS) ? bias : nullptr, residual, ldr, row_scale,
                                            rows_per_scale, y, nullptr, ldy, M, N, K, st);
@@ -1220,6 +1226,8 @@ extern "C" int mvit_linear_gelu_fwd(const void* a, int64_t lda, const void* w, c
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
     static const bool fused = getenv("MVIT_GEMM_NO_PERS") == nullptr && getenv("MVIT_GEMM_NO_BIG") == nullptr && getenv("MVIT_NO_GELU_FUSE") == nullptr;
+    if (fused && (lda & 7) == 0 && mvit_internal_linear_k96_ok(lda, M, N, K))
+        return mvit_internal_linear_k96(PP_GELU_PRE, a, lda, w, bias, y, pre, N, M, N, as_stream(stream));
     if (fused && use_pp(lda, M, N, K, PP_GELU_PRE))
         return mvit_internal_linear_pp(PP_GELU_PRE, a, lda, w, bias, nullptr, 0, nullptr, 0, y, pre, N, M, N, K, as_stream(stream));
     if (fused && N % G_BN == 0 && G_KOK(K) && (lda & 7) == 0 && 256 * lda < (1ll << 31) && (int64_t)N * K < (1ll << 31))
@@ -1259,6 +1267,8 @@ extern "C" int mvit_linear_gelu_fwd_dsave(const void* a, int64_t lda, const void
     if (!a || !w || !bias || !dact || !y || M < 0 || N <= 0 || K <= 0) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if (M == 0) return MVIT_OK;
+    if (mvit_internal_linear_k96_ok(lda, M, N, K))
+        return mvit_internal_linear_k96(PP_GELU_DER, a, lda, w, bias, y, dact, N, M, N, as_stream(stream));
     if (N % G_BN || !G_KOK(K) || (lda & 7) || 256 * lda >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return MVIT_EUNSUPPORTED;
     if (use_pp(lda, M, N, K, PP_GELU_DER))
         return mvit_internal_linear_pp(PP_GELU_DER, a, lda, w, bias, nullptr, 0, nullptr, 0, y, dact, N, M, N, K, as_stream(stream));

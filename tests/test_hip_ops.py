@@ -245,6 +245,49 @@ def test_linear_pingpong_all_epilogues(hip_lib, M, N, K):
     _close(out, (aux.float() * acc).cpu(), 1.5e-2)
 
 
+@pytest.mark.parametrize("M,N", [(128 * 300 + 77, 288), (128 * 600, 384), (128 * 257 + 1, 576), (32768, 384)])
+def test_linear_k96_resident_weights_all_epilogues(hip_lib, M, N):
+    """csrc/linear_k96.hip (K = 96, N in {288, 384, 576}, M >= 32768 route to it: qkv of blocks 0 / 1 and fc1 of block 0,
+    attention.py:231, common.py:27-31): weights resident in LDS, one persistent workgroup per CU streaming 128-row token tiles.  Bias,
+    bias + GELU and the two training pairs (GELU + pre-activation, GELU + derivative); ragged M (rows past M never stored: the canary
+    rows behind the output stay NaN), more tiles than workgroups, one- and two-pass column layouts; against fp32 torch on the same
+    16-bit operands."""
+    K = 96
+    a = _rnd(M, K, seed=71).to(torch.bfloat16).to(DEV)
+    w = _rnd(N, K, seed=72, scale=0.12).to(torch.bfloat16).to(DEV)
+    bias = _rnd(N, seed=73, scale=0.3).to(DEV)
+    acc = a.float() @ w.float().t() + bias
+
+    def buf():
+        return torch.full((M + 64, N), float("nan"), dtype=torch.bfloat16, device=DEV)      # 64 canary rows
+
+    def check_canary(t):
+        assert bool(torch.isnan(t[M:].float()).all()), "rows past M were written"
+    y = buf()
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(a), _hip.BF16, K, _hip.ptr(w), _hip.ptr(bias), None, N, None, 0, _hip.ptr(y), _hip.BF16, N, M, N, K,
+                                       _hip.EPI_BIAS, _hip.BF16, _st()))
+    _close(y[:M], acc.cpu(), 1e-2)
+    check_canary(y)
+    yb = y[:M].clone()
+    y = buf()
+    _hip.check(hip_lib.mvit_linear_fwd(_hip.ptr(a), _hip.BF16, K, _hip.ptr(w), _hip.ptr(bias), None, N, None, 0, _hip.ptr(y), _hip.BF16, N, M, N, K,
+                                       _hip.EPI_BIAS | _hip.EPI_GELU, _hip.BF16, _st()))
+    _close(y[:M], F.gelu(acc).cpu(), 1e-2)
+    check_canary(y)
+    yg = y[:M].clone()
+    pre, y = buf(), buf()
+    _hip.check(hip_lib.mvit_linear_gelu_fwd(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(pre), _hip.ptr(y), M, N, K, _hip.BF16, _st()))
+    assert torch.equal(pre[:M], yb) and torch.equal(y[:M], yg)
+    check_canary(pre), check_canary(y)
+    x = acc.clone().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    dact, y = buf(), buf()
+    _hip.check(hip_lib.mvit_linear_gelu_fwd_dsave(_hip.ptr(a), K, _hip.ptr(w), _hip.ptr(bias), _hip.ptr(dact), _hip.ptr(y), M, N, K, _hip.BF16, _st()))
+    assert torch.equal(y[:M], yg)
+    _close(dact[:M], x.grad.cpu(), 1e-2)
+    check_canary(dact), check_canary(y)
+
+
 def test_linear_rejects_bad_shapes(hip_lib):
     t = torch.zeros(64, 64, device=DEV)
     assert hip_lib.mvit_linear_fwd(_hip.ptr(t), _hip.BF16, 64, _hip.ptr(t), None, None, 0, None, 0, _hip.ptr(t), _hip.BF16,
