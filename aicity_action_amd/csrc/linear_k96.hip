@@ -144,6 +144,11 @@ __global__ __launch_bounds__(128 * NWP) void linear_k96_kernel(const bf16_t* __r
                     for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = mfma16(wf[nb], xf[mb], acc[mb][nb]);
             }
             // ---- epilogue from registers: lane = output row, quads of 4 consecutive columns; 16-byte pieces via permlane32_swap --
+            // Two outputs: ALL stores of y first, then all of y2 (the packed y2 pieces wait in 48 registers).  In a pure store stream,
+            // alternating between two matrices store by store costs a third of the write bandwidth (3.5 against 5.1 TB/s:
+            // tools/probes/store_bw, patterns 3 / 5); here the ordered form runs a steady 360 us where the alternating one ran
+            // 341 ... 430 (the same reordering in the ping-pong kernel's epilogue, whose stores are spread out anyway, was 6 % slower).
+            [[maybe_unused]] uint4 y2p[2][3][2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const int64_t m = mw + 32 * mb + r;
@@ -182,9 +187,21 @@ __global__ __launch_bounds__(128 * NWP) void linear_k96_kernel(const bf16_t* __r
                             const uint32_t b0 = pack_bf16x2(u[q + 1].x, u[q + 1].y), b1 = pack_bf16x2(u[q + 1].z, u[q + 1].w);
                             const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                             const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                            if (ok) *reinterpret_cast<uint4*>(y2 + o + 8 * (q + h)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            y2p[mb][nb][q >> 1] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         }
                     }
+                }
+            }
+            if constexpr (EPI >= K9_GELU_PRE) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int64_t m = mw + 32 * mb + r;
+                    const bool ok = !ragged || m < M;
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2)
+                            if (ok) *reinterpret_cast<uint4*>(y2 + m * ldy + nw0 + 32 * nb + 8 * (q + h)) = y2p[mb][nb][q >> 1];
                 }
             }
         }

@@ -3,6 +3,8 @@
 // 64 x 96 sub-tile in 1-KiB runs = 5.33 rows x 192 B per instruction; 2: the workgroup's 128 x 192 tile in 1-KiB runs = 2.67 rows x 384 B).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+// patterns 3 / 4: the two-output epilogue of the training fc1 (GELU + saved derivative): pattern 0 into TWO matrices alternately (3: two separate
+// buffers, 4: the two outputs side by side in one [M][2N] buffer).
 extern "C" __global__ __launch_bounds__(256) void store_bw_kernel(char* __restrict__ out, int64_t M, int N, int pattern) {
     const int ntn = N / 192;
     const int64_t tile = blockIdx.x;
@@ -19,6 +21,42 @@ extern "C" __global__ __launch_bounds__(256) void store_bw_kernel(char* __restri
 #pragma unroll
                 for (int q = 0; q < 4; q += 2)
                     *reinterpret_cast<uint4*>(out + (m0 + 64 * wm + 32 * mb + r) * pitch + (n0 + 96 * wn + 32 * nb + 8 * (q + h)) * 2) = v;
+    } else if (pattern == 3 || pattern == 4) {
+        char* out2 = pattern == 3 ? out + M * pitch + 4096 * 37 : out + pitch;
+        const int64_t p2 = pattern == 3 ? pitch : 2 * pitch;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    const int64_t o = (m0 + 64 * wm + 32 * mb + r) * p2 + (n0 + 96 * wn + 32 * nb + 8 * (q + h)) * 2;
+                    *reinterpret_cast<uint4*>(out + o) = v;
+                    *reinterpret_cast<uint4*>(out2 + o) = v;
+                }
+    } else if (pattern == 5 || pattern == 6) {     // two separate matrices: 5 = all stores of the first, then all of the second; 6 = per 32 x 32 block
+        char* out2 = out + M * pitch + 4096 * 37;
+        if (pattern == 5) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2)
+                            *reinterpret_cast<uint4*>((which ? out2 : out) + (m0 + 64 * wm + 32 * mb + r) * pitch + (n0 + 96 * wn + 32 * nb + 8 * (q + h)) * 2) = v;
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int which = 0; which < 2; ++which)
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2)
+                            *reinterpret_cast<uint4*>((which ? out2 : out) + (m0 + 64 * wm + 32 * mb + r) * pitch + (n0 + 96 * wn + 32 * nb + 8 * (q + h)) * 2) = v;
+        }
     } else if (pattern == 1) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
