@@ -452,6 +452,8 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
         if (f >= 1 && !(POOL_ABL & 2)) finalize(f - 1);
         else __syncthreads();
         if (f + 1 < T) {
+            // (the loads are issued here, not ahead of this frame's arithmetic: held across it the ten prefetch registers push the kernel
+            // over its 168-register budget -- spills -- and measured 7-11 % slower, r3; the co-resident workgroups hide the round trip)
             if (!P::DB && !(POOL_ABL & 4)) prefetch(f + 1);   // single buffer: every thread is past its tile reads (barrier above)
             commit(P::DB ? ((f + 1) & 1) : 0);
         }
