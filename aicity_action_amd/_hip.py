@@ -60,6 +60,7 @@ _SIGS = {
     "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),
     "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
     "mvit_attention_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "mvit_attention_bwd_dq_w64": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd_train": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),

@@ -31,10 +31,19 @@ _POOL_FWD_SIDE = os.environ.get("MVIT_POOL_FWD_SIDE", "0") == "1"
 _POOL_KV_BATCH = os.environ.get("MVIT_POOL_KV_BATCH", "1") != "0"
 
 
-def _skip_fused(g, act):
-    """Widening stage-transition blocks (MViTv2-B: 1, 3, 14) take the fused skip path of csrc/skip_pool.hip on the 16-bit builds."""
-    return (g.expand and not g.skip_is_identity and act != _hip.F32 and g.dim_in % 96 == 0 and g.dim_out % 96 == 0
-            and os.environ.get("MVIT_SKIP_FUSE", "1") != "0")
+_SKIP_FUSE = os.environ.get("MVIT_SKIP_FUSE", "1") != "0"      # read once
+
+
+def _skip_fused(g, act, B=1):
+    """Widening stage-transition blocks (MViTv2-B: 1, 3, 14) take the fused skip path of csrc/skip_pool.hip on the 16-bit builds.
+    The conditions mirror what mvit_proj_maxpool_fwd / _bwd accept (input widths 96 / 192 / 384, output a multiple of 96, 32-bit
+    offsets); anything else -- a 768 -> 1536 stage, a very large batch -- takes the unfused linear + max-pool pair."""
+    if not (_SKIP_FUSE and g.expand and not g.skip_is_identity and act != _hip.F32):
+        return False
+    if g.dim_in not in (96, 192, 384) or g.dim_out % 96 != 0:
+        return False
+    n_in = B * g.thw_in[0] * g.thw_in[1] * g.thw_in[2]
+    return n_in * g.dim_in < (1 << 31) and B * g.lq * g.dim_out < (1 << 30)
 
 
 def _ws(nbytes, dev):
@@ -46,9 +55,12 @@ class _Ctx(object):
 
     def __init__(self, model):
         self.m = model
-        self.L = model._lib()
-        self.act = _hip.F32 if model.precision == "fp32" else _hip.BF16
-        self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype()
+        # "auto" is resolved HERE, once per graph: inside the autograd backward grad mode is off and the property would answer
+        # "fp16" for a graph whose forward ran in bf16 (eval-mode model with grad enabled)
+        self.prec = model.precision
+        self.L = model._lib(self.prec)
+        self.act = _hip.F32 if self.prec == "fp32" else _hip.BF16
+        self.adt = torch.float32 if self.act == _hip.F32 else model._half_dtype(self.prec)
         self._red_keep = None   # workspaces pinned while a deferred-reduction queue is open (_BlockFn.backward)
         self._last_block = None  # (index, dp2, output data_ptr) of the block that ran last in this chain (forward)
         self._g16_stash = None   # (data_ptr of a stream gradient, its 16-bit scaled copy) handed from one block backward to the next
@@ -74,11 +86,11 @@ class _Ctx(object):
         return t
 
     def w(self, p):
-        return self.m._w_pair(p, self.act)[0]
+        return self.m._w_pair(p, self.act, self.prec)[0]
 
     def wt(self, p):
         """[K][N] transposed copy in the activation dtype (operand of the data-gradient GEMM)."""
-        return self.m._w_pair(p, self.act)[1]
+        return self.m._w_pair(p, self.act, self.prec)[1]
 
     # y = a . w^T (+bias)(gelu)(*row_scale)(+residual)
     def linear(self, a, w, bias, out_dtype, residual=None, gelu=False, row_scale=None, rps=0):
@@ -313,7 +325,7 @@ class _BlockFn(torch.autograd.Function):
                                         addq, act, _st()), "attention")
         r = x2
         r_full = None
-        if _skip_fused(g, act):
+        if _skip_fused(g, act, B):
             # widen + max-pool in one kernel: the full-resolution widened tensor never reaches HBM (csrc/skip_pool.hip)
             r = torch.empty(Mq, Cout, dtype=torch.float32, device=dev)
             pool_idx = torch.empty(Mq, Cout, dtype=torch.uint8, device=dev)
@@ -487,7 +499,7 @@ class _BlockFn(torch.autograd.Function):
         # ---- skip path ------------------------------------------------------------------------------------
         d_r = d_y
         extra = []
-        if _skip_fused(g, act):
+        if _skip_fused(g, act, B):
             # un-pool + data gradient in one kernel; the un-pooled gradient leaves once, 16 bit, for the weight-gradient GEMM
             d_x = torch.empty(M, Cin, dtype=torch.float32, device=dev)
             d16 = torch.empty(M, Cout, dtype=adt, device=dev)
@@ -501,7 +513,7 @@ class _BlockFn(torch.autograd.Function):
             d_rf = torch.empty(M, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_bwd_idx(_hip.ptr(r_full), _hip.ptr(d_r), _hip.ptr(d_rf), B, T, H, W, Cout, _st()), "maxpool_bwd")
             d_r = d_rf
-        if _skip_fused(g, act):
+        if _skip_fused(g, act, B):
             pass
         elif g.expand:
             dWm, dbm = hx.wgrad(x2, d_r, Cout, Cin)
@@ -615,7 +627,7 @@ def forward_train(model, clip):
         return _forward_train_one(model, clip, hx, dp_all, mask)
     for m in model.modules():                      # weight copies are (re)built once, on the caller's stream
         if isinstance(m, torch.nn.Linear) and m.weight.is_cuda and m.weight.dim() == 2 and m is not model.head.projection:
-            model._w_pair(m.weight, hx.act)
+            model._w_pair(m.weight, hx.act, hx.prec)
     model._side_streams = _hip.shared_streams(dev, ns)
     cur = torch.cuda.current_stream(dev)
     bounds = [(B * i) // ns for i in range(ns + 1)]

@@ -182,7 +182,9 @@ __device__ __forceinline__ bf16x8 b_join(bf16x4 lo, bf16x4 hi) {
                    "+v"(A[10]), "+v"(A[11]) \
                  : "n"(N))
 
-template <bool ADD_Q>
+// PRE: the forward of this shape ran on round16(q * scale * log2e) (attn_fwd_prescales_q): rebuild exactly those scores.  Otherwise
+// the forward's scores were (q . k) * scale * log2e on the unrounded q, and so are these (one multiply-add per element more).
+template <bool ADD_Q, bool PRE = true>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                              const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
     // Q is scaled by scale * log2(e) once (and rounded to the 16-bit type again) and every score accumulator starts at -lse: the scores
     // leave the MFMA chain as the exponent itself (P = exp2(S), no multiply-add per element); -delta likewise rides on the dP chain
-    {
+    if constexpr (PRE) {
         auto scl = [&](short lo, short hi) { return pack_bf16x2(bf16_to_f32((bf16_t)lo) * scale_log2e, bf16_to_f32((bf16_t)hi) * scale_log2e); };
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     }
     asm volatile("" : "+v"(lse), "+v"(dlt));
     const float ndlt = -dlt, nlse = -lse;
+    const float s_init = PRE ? nlse : 0.f;       // !PRE: -lse joins in the exponent's multiply-add instead
 
     // K / V row fragment of k-step ks: row r, 16-B chunk (2ks + h + rot(r)) mod 12 with rot <= 3: k-steps 0..3 never wrap (immediate
     // offsets from one lane address), k-steps 4 and 5 each get their own
@@ -320,14 +323,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kbase + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    s[kb][i] = key < Lk ? nlse : -INFINITY;
+                    s[kb][i] = key < Lk ? s_init : -INFINITY;
                     dp[kb][i] = ndlt;
                 }
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { s[kb][i] = nlse; dp[kb][i] = ndlt; }       // S c - lse and dP^T - delta come out of the MFMA chains
+                for (int i = 0; i < 16; ++i) { s[kb][i] = s_init; dp[kb][i] = ndlt; }       // S c - lse and dP^T - delta come out of the MFMA chains
         }
         // K / V row fragments: inline-asm reads two k-steps ahead of the MFMAs with counted waits (LDS returns in order)
         bf16x8 kf[3], vf[3];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #define DQ_RD(SL, A, OFF, KB) { kf[SL] = b_rd128<OFF + (KB) * 32 * B_ROWB>(A); vf[SL] = b_rd128<OFF + B_T * B_ROWB + (KB) * 32 * B_ROWB>(A); }
 #define DQ_WAIT(SL, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[SL]), "+v"(vf[SL]) : "n"(N))
 #define DQ_MM(SL, KS, KB) { s[KB] = mfma16(kf[SL], qf[KS], s[KB]); dp[KB] = mfma16(vf[SL], dof[KS], dp[KB]); }
-#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(s[KB][I]); dsv[KB][I] = p_ * dp[KB][I]; }
+#define DQ_VAL(KB, I) { const float p_ = __builtin_amdgcn_exp2f(PRE ? s[KB][I] : fmaf(s[KB][I], scale_log2e, nlse)); dsv[KB][I] = p_ * dp[KB][I]; }
 #define DQ_SB __builtin_amdgcn_sched_barrier(0);
 #define TRQ(A, S16) \
         A[0] = b_tr16<(S16) * 16 * B_ROWB>(t_lo[0] + so); A[1] = b_tr16<(S16) * 16 * B_ROWB>(t_hi[0] + so); \
@@ -807,10 +810,10 @@ extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, 
 }
 
 // the 64-query form of pass A by itself (tests, tools): delta = mvit_attention_bwd's workspace head (fp32 [B*heads*Lq])
-extern "C" int mvit_internal_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
+extern "C" int mvit_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                                                   void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q, void* stream) {
     if (!q || !k || !v || !dout || !lse || !delta || !dq || Lk < 64 || Lq < 1) return MVIT_EINVAL;
-    static bool done = false;
+    static DevFlags done_tab; bool& done = dev_flag(done_tab);
     if (!done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; done = true; }
     const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, delta, dq, B, heads, Lq, Lk, scale, scale * 1.44269504088896340736f, add_q, as_stream(stream));
     if (rc != MVIT_OK) return rc;
@@ -864,31 +867,35 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         // pass A in the 64-queries-per-wave form (attention_bwd_w64.hip) only on request (MVIT_ATT_DQ_W64=1): it measured 4-12 % behind
         // the 32-query kernel below (profiles/r3_attn_dq_w64.txt)
         static const bool dq_w64_env = getenv("MVIT_ATT_DQ_W64") && atoi(getenv("MVIT_ATT_DQ_W64")) != 0;
-        const bool dq_w64 = dq_w64_env && Lk >= 64 && Lq >= 128;
+        const bool dq_w64 = dq_w64_env && attn_fwd_prescales_q(Lq, Lk);      // (that kernel always rebuilds pre-scaled scores)
         if (dq_w64) {
-            static bool wattr_done = false;
+            static DevFlags wattr_done_tab; bool& wattr_done = dev_flag(wattr_done_tab);
             if (!wattr_done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
             const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, workspace, dq, B, heads, Lq, Lk, scale, sl2, add_q, st);
             if (rc != MVIT_OK) return rc;
             MVIT_LAUNCH_CHECK();
         }
         dim3 gq((Lq + 127) / 128, B * heads);
-        static bool dq_attr_done = false;
+        static DevFlags dq_attr_done_tab; bool& dq_attr_done = dev_flag(dq_attr_done_tab);
         if (!dq_attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess)
                 return MVIT_ELAUNCH;
             dq_attr_done = true;
         }
+        // the dQ pass exponentiates the scores the forward built its lse on: pre-scaled 16-bit queries when that ran in the 64-query
+        // kernel, (q . k) * scale * log2e otherwise (short sequences, MVIT_ATT_W64=0)
+        const bool pre = attn_fwd_prescales_q(Lq, Lk);
+#define DQ_LAUNCH(AQ, PR) hipLaunchKernelGGL((attn_bwd_dq_kernel<AQ, PR>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k, \
+                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2)
         if (dq_w64) {}
-        else if (add_q)
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
-        else
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2);
+        else if (add_q) { if (pre) DQ_LAUNCH(true, true); else DQ_LAUNCH(true, false); }
+        else { if (pre) DQ_LAUNCH(false, true); else DQ_LAUNCH(false, false); }
+#undef DQ_LAUNCH
         MVIT_LAUNCH_CHECK();
-        static bool dkv_attr_done = false;
+        static DevFlags dkv_attr_done_tab; bool& dkv_attr_done = dev_flag(dkv_attr_done_tab);
         if (!dkv_attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess)

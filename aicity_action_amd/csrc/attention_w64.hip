@@ -1,6 +1,6 @@
 // Fused pooled attention forward, head_dim 96, 64 queries per wave, ONE wave per SIMD, software-pipelined by hand
-// (reference math: slowfast/models/attention.py:267-279).  Selected by MVIT_ATT_W64=1 (see attention.hip); the 32-query kernels of
-// attention.hip remain the default until this form wins inside the model.
+// (reference math: slowfast/models/attention.py:267-279).  The DEFAULT forward for Lq >= 128, Lk >= 64 in the 16-bit builds (attention.hip routes here;
+// MVIT_ATT_W64=0 selects the 32-query kernels of attention.hip for A/B runs; short sequences always use those).
 //
 // Why this shape: in the 32-query kernels every K / V fragment read from LDS feeds one MFMA and a K/V tile is streamed once per
 // 128 queries; their timing ablations show the fragment reads, the LDS-DMA and the MFMAs costing their own

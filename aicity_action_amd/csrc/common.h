@@ -202,6 +202,21 @@ static inline bool side_join(SideStream* s, hipStream_t st) {
     return s && hipEventRecord(s->ev_join, s->side) == hipSuccess && hipStreamWaitEvent(st, s->ev_join, 0) == hipSuccess;
 }
 
+// Lazily set per-kernel state (hipFuncSetAttribute for > 64 KiB of dynamic LDS, the CU count behind a persistent grid) is a property
+// of the DEVICE the call runs on, not of the process: one slot per device ordinal.
+struct DevFlags { bool f[16] = {}; };
+static inline bool& dev_flag(DevFlags& d) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return d.f[dev & 15];
+}
+struct DevInts { int v[16] = {}; };
+static inline int& dev_int(DevInts& d) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return d.v[dev & 15];
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // deterministic column sums of a [nparts][width] fp32 partial table (backward_rowops.hip)

@@ -220,7 +220,8 @@ static int k96_launch(const void* a, int64_t lda, const void* w, const float* bi
                       hipStream_t st) {
     constexpr int N = 96 * NWP * PASSES;
     constexpr int SMEM = N * K9_ROWB + 2 * K9_ABYTES;
-    static int ncu = 0;
+    static DevInts ncu_tab;
+    int& ncu = dev_int(ncu_tab);
     if (!ncu) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)

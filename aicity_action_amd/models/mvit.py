@@ -186,27 +186,30 @@ class MViT(nn.Module):
             raise ValueError("cfg.HIP.PRECISION must be 'auto', 'bf16', 'fp16' or 'fp32', got %r" % (p,))
         return p
 
-    def _lib(self):
-        return _hip.lib("fp16" if self.precision == "fp16" else "bf16")
+    # `prec` below: a precision resolved ONCE by the caller ("auto" depends on grad mode, which is off inside an autograd
+    # backward: a graph built in bf16 must keep reading the bf16 copies and the bf16 library -- autograd._Ctx pins it).
+    def _lib(self, prec=None):
+        return _hip.lib("fp16" if (prec or self.precision) == "fp16" else "bf16")
 
-    def _half_dtype(self):
-        return torch.float16 if self.precision == "fp16" else torch.bfloat16
+    def _half_dtype(self, prec=None):
+        return torch.float16 if (prec or self.precision) == "fp16" else torch.bfloat16
 
-    def _w(self, param, act):
+    def _w(self, param, act, prec=None):
         """Weight in the activation dtype of the MFMA path (fp32 master -> cached bf16 copy)."""
         if act == _hip.F32:
             return param
-        key = (self.precision, id(param))
+        prec = prec or self.precision
+        key = (prec, id(param))
         ent = self._bf16_cache.get(key)
         if ent is None or ent[0] != param._version or ent[1].device != param.device:
-            buf = torch.empty(param.shape, dtype=self._half_dtype(), device=param.device)
+            buf = torch.empty(param.shape, dtype=self._half_dtype(prec), device=param.device)
             st = torch.cuda.current_stream().cuda_stream
-            _hip.check(self._lib().mvit_cast_f32_to_bf16(_hip.ptr(param), _hip.ptr(buf), param.numel(), st), "cast")
+            _hip.check(self._lib(prec).mvit_cast_f32_to_bf16(_hip.ptr(param), _hip.ptr(buf), param.numel(), st), "cast")
             ent = (param._version, buf)
             self._bf16_cache[key] = ent
         return ent[1]
 
-    def _w_pair(self, param, act):
+    def _w_pair(self, param, act, prec=None):
         """(W, W^T) of a 2-D GEMM weight in the activation dtype (training: the forward reads W, the data-gradient GEMM W^T).
         The copies of ALL GEMM weights live in persistent buffers and are refreshed together by one multi-tensor kernel whenever
         any parameter's version counter moved (optimizer step, load_state_dict)."""
@@ -217,28 +220,30 @@ class MViT(nn.Module):
                 ent = (param._version, param, param.detach().t().contiguous())
                 self._bf16_cache[key] = ent
             return ent[1], ent[2]
-        st = self._pairs_state()
+        prec = prec or self.precision
+        st = self._pairs_state(prec)
         ent = st["by_id"].get(id(param))
         if ent is None:                             # not one of the block GEMM weights: single-tensor path
-            key = ("pair", self.precision, id(param))
+            key = ("pair", prec, id(param))
             e2 = self._bf16_cache.get(key)
             if e2 is None or e2[0] != param._version or e2[1].device != param.device:
                 R, C = param.shape
-                w = torch.empty(R, C, dtype=self._half_dtype(), device=param.device)
-                wt = torch.empty(C, R, dtype=self._half_dtype(), device=param.device)
-                _hip.check(self._lib().mvit_cast_transpose_f32_to_bf16(_hip.ptr(param), _hip.ptr(w), _hip.ptr(wt), R, C,
+                w = torch.empty(R, C, dtype=self._half_dtype(prec), device=param.device)
+                wt = torch.empty(C, R, dtype=self._half_dtype(prec), device=param.device)
+                _hip.check(self._lib(prec).mvit_cast_transpose_f32_to_bf16(_hip.ptr(param), _hip.ptr(w), _hip.ptr(wt), R, C,
                                                                        torch.cuda.current_stream().cuda_stream), "cast_t")
                 e2 = (param._version, w, wt)
                 self._bf16_cache[key] = e2
             return e2[1], e2[2]
         if ent[0]._version != ent[3]:
-            self._refresh_pairs(st)
+            self._refresh_pairs(st, prec)
         return ent[1], ent[2]
 
-    def _pairs_state(self):
+    def _pairs_state(self, prec=None):
         """Persistent 16-bit (W, W^T) buffers + device descriptor table of every block GEMM weight, per (precision, device)."""
+        prec = prec or self.precision
         dev = self.pos_embed_spatial.device
-        key = ("pairs", self.precision, dev)
+        key = ("pairs", prec, dev)
         st = self._bf16_cache.get(key)
         if st is not None:
             return st
@@ -249,14 +254,14 @@ class MViT(nn.Module):
             if hasattr(blk, "proj_max_pool"):
                 ws.append(blk.proj_max_pool.weight)
             plist += ws
-        L = self._lib()
+        L = self._lib(prec)
         dt = np.dtype([("src", "u8"), ("dst", "u8"), ("dst_t", "u8"), ("rows", "i4"), ("cols", "i4"), ("first", "i4"), ("pad", "i4")])
         assert L.mvit_cast_desc_bytes() == dt.itemsize
         by_id, rec, first = {}, [], 0
         for p in plist:
             R, C = p.shape
-            w = torch.empty(R, C, dtype=self._half_dtype(), device=dev)
-            wt = torch.empty(C, R, dtype=self._half_dtype(), device=dev)
+            w = torch.empty(R, C, dtype=self._half_dtype(prec), device=dev)
+            wt = torch.empty(C, R, dtype=self._half_dtype(prec), device=dev)
             by_id[id(p)] = [p, w, wt, -1]            # [param, W, W^T, version the copies were made from]
             rec.append((p.data_ptr(), w.data_ptr(), wt.data_ptr(), R, C, first, 0))
             first += ((R + 63) // 64) * ((C + 63) // 64)
@@ -265,15 +270,16 @@ class MViT(nn.Module):
         self._bf16_cache[key] = st
         return st
 
-    def _refresh_pairs(self, st):
+    def _refresh_pairs(self, st, prec=None):
+        prec = prec or self.precision
         ents = list(st["by_id"].values())
         if [e[0].data_ptr() for e in ents] != st["ptrs"]:        # parameters were re-allocated (.to(), .cuda()): rebuild the table
-            del self._bf16_cache[("pairs", self.precision, self.pos_embed_spatial.device)]
-            st2 = self._pairs_state()
+            del self._bf16_cache[("pairs", prec, self.pos_embed_spatial.device)]
+            st2 = self._pairs_state(prec)
             st.clear()
             st.update(st2)
             ents = list(st["by_id"].values())
-        _hip.check(self._lib().mvit_cast_transpose_multi(_hip.ptr(st["table"]), st["n"], st["tiles"],
+        _hip.check(self._lib(prec).mvit_cast_transpose_multi(_hip.ptr(st["table"]), st["n"], st["tiles"],
                                                          torch.cuda.current_stream().cuda_stream), "cast_multi")
         for e in ents:
             e[3] = e[0]._version
@@ -443,7 +449,7 @@ class MViT(nn.Module):
         # 5. skip path: channel expand on the un-normed x, then max-pool     attention.py:424-432
         r = x.view(M, Cin)
         from ..autograd import _skip_fused
-        if _skip_fused(g, act):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
+        if _skip_fused(g, act, B):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(r), _hip.ptr(self._w(blk.proj_max_pool.weight, act)),
                                                _hip.ptr(blk.proj_max_pool.bias), _hip.ptr(rp), None, None, B, T, H, W, Cin, Cout, act, st),
@@ -451,7 +457,7 @@ class MViT(nn.Module):
             r = rp
         elif g.expand:
             r = self._linear(L, st, act, r, _hip.F32, blk.proj_max_pool, torch.float32, M)
-        if not g.skip_is_identity and not _skip_fused(g, act):
+        if not g.skip_is_identity and not _skip_fused(g, act, B):
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r), _hip.ptr(rp), B, T, H, W, Cout, st), "maxpool")
             r = rp

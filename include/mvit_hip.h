@@ -176,6 +176,12 @@ int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk);
 int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                        const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
+/* The opt-in 64-query form of the dQ pass by itself (MVIT_ATT_DQ_W64=1 selects it inside mvit_attention_bwd; measured behind the
+ * default 32-query pass, kept for A/B runs and its parity test).  16-bit builds only, Lk >= 64.  delta: fp32 [B*heads*Lq] =
+ * rowsum(dout * out), i.e. the head of the workspace mvit_attention_bwd has filled.  (slowfast/models/attention.py:267-279) */
+int mvit_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse,
+                              const float* delta, void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q,
+                              void* stream);
 
 /* Backward of mvit_pool_conv_ln_fwd: dout [B][heads][T*Ho*Wo][96] -> the (which) slice of dqkv [B][T*H*W][ld]
  * (fully overwritten), dw [96][27] (accumulated), dgamma/dbeta.  dconv: scratch shaped like dout.

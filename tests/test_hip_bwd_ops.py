@@ -283,9 +283,7 @@ def test_attention_bwd_dq_64_query_form(hip_lib, B, h, Lq, Lk, add_q):
     ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk) // 4, device=DEV)
     _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod), _hip.ptr(dq0),
                                           _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, add_q, _hip.BF16, _st()))
-    fn = hip_lib.mvit_internal_attention_bwd_dq_w64          # not part of the C-ABI header: the delta vector is the workspace's head
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    fn = hip_lib.mvit_attention_bwd_dq_w64          # delta = the head of the workspace mvit_attention_bwd has just filled
     dq1 = torch.full_like(qd, float("nan"))
     _hip.check(fn(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(dod), _hip.ptr(lse), _hip.ptr(ws), _hip.ptr(dq1), B, h, Lq, Lk, scale, add_q,
                   _st()))

@@ -337,3 +337,46 @@ def test_small_model_with_peaked_attention_against_the_oracle(gain):
     cos = float((a @ b) / (a.norm() * b.norm()))
     print("[peaked attention, gain %.1f bf16] logits max|diff| %.2e  |g| %.4f (oracle %.4f)  gradient cosine %.5f" % (gain, err, a.norm(), b.norm(), cos))
     assert err <= 3e-2 and cos >= 0.995 and abs(float(a.norm() / b.norm()) - 1.0) <= 0.05
+
+
+def test_eval_mode_backward_with_auto_precision_keeps_one_arithmetic():
+    """HIP.PRECISION "auto" answers bf16 while a graph is being built and fp16 with grad mode off -- which is the mode autograd runs
+    `backward` in.  An eval()-mode model called with grad enabled must run its whole graph (forward AND backward: the 16-bit W / W^T
+    copies, the kernel library) in the arithmetic resolved at graph construction.  Checked against autograd over the oracle, and
+    against the same graph built with the precision pinned to bf16 (bit-identical gradients)."""
+    import copy
+    import os
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvit_oracle as O
+    from aicity_action_amd.config import load_config
+
+    opts = ["MVIT.DEPTH", 4, "MVIT.DIM_MUL", [[1, 2.0], [3, 2.0]], "MVIT.HEAD_MUL", [[1, 2.0], [3, 2.0]],
+            "MVIT.POOL_Q_STRIDE", [[1, 1, 2, 2], [3, 1, 2, 2]], "MVIT.POOL_KV_STRIDE_ADAPTIVE", [1, 4, 4], "MVIT.DROPPATH_RATE", 0.0,
+            "MODEL.DROPOUT_RATE", 0.0, "DATA.NUM_FRAMES", 4, "DATA.TRAIN_CROP_SIZE", 64, "DATA.TEST_CROP_SIZE", 64, "NUM_GPUS", 1]
+    clip = synth_clip(2, 4, 64, 21)
+    w = torch.linspace(-1.0, 1.0, 2 * 18).reshape(2, -1)
+    grads = {}
+    for prec in ("auto", "bf16"):
+        cfg = load_config(os.path.join(ROOT, "configs", "Aicity", "MVITV2_FULL_B_16x4_CONV.yaml"), opts + ["HIP.PRECISION", prec])
+        mv = copy.deepcopy(cfg.MVIT.to_dict())
+        model = build_model(cfg).eval()
+        load_synth_weights(model, 11)
+        with torch.no_grad():                    # an inference call first: under "auto" it builds the fp16 weight copies
+            model([clip.cuda()])
+        assert model.precision == ("bf16" if prec == "bf16" else "bf16")     # grad mode on + trainable parameters
+        probs, lg = model([clip.cuda()], return_logits=True)
+        (lg * w.cuda()).sum().backward()
+        grads[prec] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    for k in grads["auto"]:
+        assert torch.equal(grads["auto"][k], grads["bf16"][k]), "auto-precision backward differs from the pinned bf16 graph: " + k
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    _, o_lg = O.forward(sd, clip, mv, training=False, head_act=False)
+    (o_lg * w).sum().backward()
+    a = torch.cat([grads["auto"][k].flatten().cpu() for k, _ in model.named_parameters()]).double()
+    b = torch.cat([sd[k].grad.flatten() for k, _ in model.named_parameters()]).double()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    print("[eval + grad, auto] gradient cosine vs oracle %.5f, |g| %.4f (oracle %.4f)" % (cos, a.norm(), b.norm()))
+    assert cos >= 0.995 and abs(float(a.norm() / b.norm()) - 1.0) <= 0.05
