@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|fwd] [--batch 8] [--crop 448]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the environment) `bench.py --gpus N` starts the second form
+itself as a child process -- before anything in this process has touched the GPU -- on 127.0.0.1 and a free port, lets the ranks
+print (rank 0: the ONE JSON line) and exits with the launcher's return code (non-zero if any rank failed).  The reference starts its
+ranks the same way: one spawned process per GPU from the entry script (slowfast/utils/misc.py:292-322, multiprocessing.py:9-68).
+
 A "step" is one pass of the hot path over one batch of synthetic clips per GPU ([8,3,16,448,448] N(0,1),
 generated on the device before the timed region; random-init weights from the seeded generator).
   --mode train (default; BASELINE.json's metric is fwd+bwd): forward (drop-path 0.4, head dropout 0.5) + soft-target CE
@@ -45,6 +50,23 @@ def attention_flops(geoms, B):
     return [4.0 * B * g.heads * g.lq * g.lk * 96 for g in geoms]
 
 
+def self_launch(n):
+    """`bench.py --gpus N` without an external launcher: run torch.distributed.run with N ranks as a CHILD process (this process has
+    not imported torch and never touches the GPU, so nothing is exec'ed over an initialised HIP runtime) and hand back its return
+    code; the ranks inherit stdout / stderr, so rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")                  # torch.distributed.run would set 1 (and warn); the CPU legs are rank-0, N = 1 only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +86,8 @@ def main():
     args = ap.parse_args()
     if args.precision is None:
         args.precision = "bf16" if args.mode in ("train", "loop") else "fp16"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -76,8 +100,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     ndev = torch.cuda.device_count()
     dev_index = local_rank if local_rank < ndev else 0      # a launcher that narrows each rank's visibility to one GPU
     torch.cuda.set_device(dev_index)
@@ -191,7 +214,12 @@ def main():
         iv = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
         ev_ms = iv[len(iv) // 2]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank = [{"rank": 0, "device": dev_index, "ms_per_step": round(dt / args.steps * 1e3, 4)}]
     if world > 1:
+        mine = torch.tensor([dt, float(dev_index)], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": i, "device": int(e[1].item()), "ms_per_step": round(e[0].item() / args.steps * 1e3, 4)} for i, e in enumerate(every)]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     assert torch.isfinite(out).all()
@@ -448,6 +476,10 @@ def main():
             "model_roofline": {"bound": "mfma", "achieved": round(clips_per_s / world * gf / 1e3, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(clips_per_s / world * gf / 1e3 / peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
+            "world_size": dist.get_world_size() if world > 1 else 1,      # as the process group saw it
+            "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+            "ranks": per_rank, "ms_per_step_rank_min": min(r_["ms_per_step"] for r_ in per_rank),
+            "ms_per_step_rank_max": max(r_["ms_per_step"] for r_ in per_rank),
         }
         if args.mode == "window":
             line["config"]["workload"] = ("sliding-window inference: 3 views x 900 frames 540x960 uint8 (synthetic), 57 windows/view of "

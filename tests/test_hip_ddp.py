@@ -171,6 +171,31 @@ def test_bench_script_two_ranks_gloo_on_one_gpu():
     assert d["config"]["parallelism"].startswith("dp2")
 
 
+def test_bench_script_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO external launcher and no WORLD_SIZE in the environment (what a driver's SCALE leg may run):
+    bench.py starts torch.distributed.run itself as a child process, rank 0 prints the one JSON line, the return code is the
+    launcher's.  Two gloo ranks on this box's one GPU."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MVIT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-kernel-timing", "--no-forward-record"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"].startswith("gloo") and len(d["ranks"]) == 2
+    assert [r_["rank"] for r_ in d["ranks"]] == [0, 1] and d["ms_per_step_rank_max"] == d["ms_per_step"]
+    assert d["config"]["global_batch"] == 16 and d["value"] > 0
+    # a failing rank must surface as a non-zero return code, not as a missing line
+    bad = subprocess.run(cmd, env=dict(env, MVIT_HIP_LIB="/nonexistent/libmvit_hip.so"), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
 def test_ddp_bf16_gradient_payload_hook():
     """HIP.DDP_BF16_GRADS: the all-reduce payload is compressed to bf16 (70.6 MB instead of 141 MB per step) and decompressed into
     the fp32 gradients; on one rank the result is the gradient rounded through bf16."""

@@ -181,3 +181,34 @@ def test_no_weight_decay_grouping_follows_the_module_name_rule():
         decay, no_decay = param_groups(m, cfg)
         assert (len(decay), len(no_decay)) == (119, 231)
         assert {"pos_embed_spatial", "pos_embed_temporal"} <= {n for n, _ in decay}
+
+
+def test_bench_self_launch_builds_the_launcher_command_without_touching_the_gpu(monkeypatch):
+    """bench.py --gpus N without WORLD_SIZE: the parent must only start `python -m torch.distributed.run ... bench.py <same args>` as a
+    child (127.0.0.1, a free port, N ranks) and return its code -- it must not import torch (an exec / fork of a process that has
+    initialised HIP takes the machine down on this pool)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    import pytest as _pt
+    with _pt.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7                                  # the launcher's return code is bench.py's
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
