@@ -29,6 +29,9 @@ _SIGS = {
     "mvit_strerror": (ctypes.c_char_p, [c_i]),
     "mvit_layernorm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
     "mvit_linear_fwd": (c_i, [c_p, c_i, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_l, c_l, c_i, c_i, c_i, c_i, c_p]),
+    "mvit_mlp_fused_pack_bytes": (c_l, [c_i, c_i]),
+    "mvit_mlp_fused_pack": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "mvit_mlp_fused_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "mvit_maxpool_skip_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -88,6 +88,10 @@ def _unsupported(cond, what):
         raise NotImplementedError("MViT (HIP path): %s is not supported" % what)
 
 
+# the fused block tail (csrc/mlp_fused.hip) for the inference forward; MVIT_MLP_FUSE=0 keeps LayerNorm + fc1 + fc2 as three launches (A/B runs)
+_MLP_FUSE = os.environ.get("MVIT_MLP_FUSE", "1") != "0"
+
+
 @MODEL_REGISTRY.register()
 class MViT(nn.Module):
     def __init__(self, cfg):
@@ -318,8 +322,12 @@ class MViT(nn.Module):
         dev = clip.device
         self._side_streams = _hip.shared_streams(dev, ns)       # one set per process and device (see _hip.shared_streams)
         act = _hip.F32 if self.precision == "fp32" else _hip.BF16
+        fused = set()
+        for blk in self.blocks:                    # packed block-tail weights: built once, on the caller's stream
+            if self._mlp_packed(blk, act) is not None:
+                fused.update((id(blk.mlp.fc1), id(blk.mlp.fc2)))
         for m in self.modules():                   # 16-bit weight copies are built once, on the caller's stream
-            if isinstance(m, nn.Linear) and m.weight.is_cuda:
+            if isinstance(m, nn.Linear) and m.weight.is_cuda and id(m) not in fused:
                 self._w(m.weight, act)
         cur = torch.cuda.current_stream(dev)
         outs = []
@@ -380,6 +388,30 @@ class MViT(nn.Module):
         if self.training and not self.use_act_in_train:
             return logits
         return probs
+
+    def _mlp_packed(self, blk, act, prec=None):
+        """The block's norm2 / fc1 / fc2 weights in the layout of the fused block-tail kernel (mvit_mlp_fused_pack: 16-bit chunk images,
+        LayerNorm's affine folded into fc1), cached per weight version; None where that kernel does not apply (fp32 path, widths
+        other than 96 / 192 / 384, MVIT_MLP_FUSE=0): the caller then runs LayerNorm + two GEMM launches."""
+        if act == _hip.F32 or not _MLP_FUSE:
+            return None
+        fc1, fc2, n2 = blk.mlp.fc1, blk.mlp.fc2, blk.norm2
+        hid, C = fc1.weight.shape
+        if C not in (96, 192, 384) or hid != 4 * C or fc1.bias is None or fc2.bias is None:
+            return None
+        prec = prec or self.precision
+        src = (fc1.weight, fc1.bias, n2.weight, n2.bias, fc2.weight)
+        ver = tuple((t._version, t.data_ptr()) for t in src)
+        key = ("mlp", prec, id(blk))
+        ent = self._bf16_cache.get(key)
+        if ent is None or ent[0] != ver:
+            Lb = self._lib(prec)
+            buf = torch.empty(Lb.mvit_mlp_fused_pack_bytes(C, hid), dtype=torch.uint8, device=fc1.weight.device)
+            _hip.check(Lb.mvit_mlp_fused_pack(_hip.ptr(fc1.weight), _hip.ptr(fc1.bias), _hip.ptr(n2.weight), _hip.ptr(n2.bias),
+                                              _hip.ptr(fc2.weight), _hip.ptr(buf), C, hid, torch.cuda.current_stream().cuda_stream), "mlp_pack")
+            ent = (ver, buf)
+            self._bf16_cache[key] = ent
+        return ent[1]
 
     def _linear(self, L, st, act, a, a_dt, lin, out_dtype, M, residual=None, gelu=False, w=None, b=None):
         weight = lin.weight if w is None else w
@@ -465,6 +497,12 @@ class MViT(nn.Module):
         y = self._linear(L, st, act, o, act, at.proj, torch.float32, B * Lq, residual=r)
         del o, r
         # 7-9. x_out = y + fc2(gelu(fc1(LN2(y))))                            attention.py:436-445
+        pk = self._mlp_packed(blk, act)
+        if pk is not None:                 # one kernel: the [M, 4C] hidden never reaches HBM (csrc/mlp_fused.hip)
+            out = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(y), _hip.ptr(pk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out), B * Lq, Cout,
+                                            blk.mlp.fc1.weight.shape[0], blk.norm2.eps, act, st), "mlp_fused")
+            return out.view(B, Lq, Cout)
         vn = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
         _hip.check(L.mvit_layernorm_fwd(_hip.ptr(y), _hip.ptr(blk.norm2.weight), _hip.ptr(blk.norm2.bias), _hip.ptr(vn),
                                         B * Lq, Cout, blk.norm2.eps, act, st), "norm2")

@@ -71,6 +71,20 @@ int mvit_linear_fwd(const void* a, int a_dtype, int64_t lda, const void* w, cons
                     void* y, int out_dtype, int64_t ldy, int64_t M, int N, int K, int epilogue,
                     int act_dtype, void* stream);
 
+/* The block tail in one kernel (inference, 16-bit builds):  out = x + fc2(GELU_erf(fc1(LayerNorm(x))))
+ * -- slowfast/models/attention.py:436-445 (x + drop_path(mlp(norm2(x))), drop-path = identity in eval mode) with Mlp.forward of
+ * slowfast/models/common.py:26-34.  The [M][hidden] activation never reaches HBM (csrc/mlp_fused.hip).
+ *   x, out: fp32 [M][C] (out may alias x: a workgroup reads and writes its own rows only); C in {96, 192, 384}, hidden = 4 C;
+ *   packed: the weights re-laid once per weight version by mvit_mlp_fused_pack into mvit_mlp_fused_pack_bytes(C, hidden) bytes:
+ *           per chunk of 32 hidden units the 16-bit fc1 rows (LayerNorm's gamma folded in) and fc2 columns in the kernel's LDS
+ *           layout, then b1' = b1 + W1 beta (fp32 [hidden]);  w1 fp32 [hidden][C], w2 fp32 [C][hidden], b2 fp32 [C].
+ * Returns MVIT_EUNSUPPORTED for other shapes / act_dtype == MVIT_F32: callers keep mvit_layernorm_fwd + two mvit_linear_fwd. */
+int64_t mvit_mlp_fused_pack_bytes(int C, int hidden);
+int mvit_mlp_fused_pack(const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2,
+                        void* packed, int C, int hidden, void* stream);
+int mvit_mlp_fused_fwd(const float* x, const void* packed, const float* b2, float* out, int64_t M, int C, int hidden,
+                       float eps, int act_dtype, void* stream);
+
 /* Pooling conv + LayerNorm of one of q/k/v for all heads (attention_pool, conv variant:
  * slowfast/models/attention.py:12-83 with the Conv3d of :172-212 and LayerNorm(eps 1e-5) of
  * :185,199,213).  Input is the fused qkv activation [B][T*H*W][ld] (act-typed); channel of

@@ -482,3 +482,67 @@ def test_head_split_round_trip(hip_lib, act):
     back = torch.zeros_like(qkv)
     _hip.check(hip_lib.mvit_head_split_bwd(_hip.ptr(out), _hip.ptr(back), 3 * C, C, B, h, N, act, _st()))
     assert torch.equal(back[:, :, C:2 * C], qkv[:, :, C:2 * C]) and float(back[:, :, :C].abs().max()) == 0.0
+
+
+def _mlp_fused_case(L, half, M, C, seed, wscale=0.05):
+    """out = x + fc2(GELU(fc1(LN(x)))) through mvit_mlp_fused_pack / _fwd of library L (16-bit type `half`) and the fp32 torch reference
+    (slowfast/models/attention.py:436-445, common.py:26-34)."""
+    hid = 4 * C
+    x = _rnd(M, C, seed=seed) * 1.5 + 0.3
+    gam, bet = 1 + 0.2 * _rnd(C, seed=seed + 1), 0.1 * _rnd(C, seed=seed + 2)
+    w1, b1 = _rnd(hid, C, seed=seed + 3) * wscale, 0.1 * _rnd(hid, seed=seed + 4)
+    w2, b2 = _rnd(C, hid, seed=seed + 5) * wscale, 0.1 * _rnd(C, seed=seed + 6)
+    ref_mlp = F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), gam, bet, 1e-6), w1, b1)), w2, b2)
+    d = [t.to(DEV) for t in (x, gam, bet, w1, b1, w2, b2)]
+    nb = L.mvit_mlp_fused_pack_bytes(C, hid)
+    assert nb == (hid // 32) * 128 * C + 4 * hid
+    packed = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _hip.check(L.mvit_mlp_fused_pack(_hip.ptr(d[3]), _hip.ptr(d[4]), _hip.ptr(d[1]), _hip.ptr(d[2]), _hip.ptr(d[5]), _hip.ptr(packed), C, hid, _st()))
+    out = torch.full((M, C), float("nan"), device=DEV)
+    _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(d[0]), _hip.ptr(packed), _hip.ptr(d[6]), _hip.ptr(out), M, C, hid, 1e-6, _hip.BF16, _st()))
+    torch.cuda.synchronize()
+    got = out.cpu() - x                     # the MLP branch by itself: the residual would hide its error
+    return got, ref_mlp, d, packed
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,C", [(392, 384), (128, 384), (1, 384), (6272 + 77, 384), (256, 192), (25088 + 3, 192), (65, 192),
+                                 (256, 96), (100352 + 129, 96), (31, 96)])
+def test_mlp_fused_forward(half, M, C):
+    """Every (rows, width) family of the model (stage 1-3 block tails), ragged row counts on every tile size, both 16-bit builds,
+    against LayerNorm -> Linear -> erf-GELU -> Linear in fp32."""
+    L = _hip.lib(half)
+    got, ref, _, _ = _mlp_fused_case(L, half, M, C, seed=40 + C // 96)
+    assert torch.isfinite(got).all()
+    tol = 2e-2 if half == "bf16" else 3e-3
+    _close(got, ref, tol)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print("[mlp_fused %s M=%d C=%d] max|err| %.3e (scale %.2f)  relative L2 %.2e" % (half, M, C, (got - ref).abs().max().item(), ref.abs().max().item(), rel))
+    assert rel <= (6e-3 if half == "bf16" else 8e-4)
+
+
+@pytest.mark.parametrize("C", [96, 192, 384])
+def test_mlp_fused_rows_do_not_depend_on_the_batch(C):
+    """A token's result depends on its own row only: the same rows inside a short and inside a long launch (different tiles,
+    different positions in a tile) are bit-identical -- what the window pipeline's batch-invariance tests rely on; out may alias x."""
+    L = _hip.lib("fp16")
+    hid = 4 * C
+    got_a, _, d, packed = _mlp_fused_case(L, "fp16", 700, C, seed=77)
+    xs = d[0][123:123 + 300].contiguous()
+    out = torch.empty_like(xs)
+    _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(xs), _hip.ptr(packed), _hip.ptr(d[6]), _hip.ptr(out), 300, C, hid, 1e-6, _hip.BF16, _st()))
+    full = torch.empty_like(d[0])
+    _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(d[0]), _hip.ptr(packed), _hip.ptr(d[6]), _hip.ptr(full), 700, C, hid, 1e-6, _hip.BF16, _st()))
+    assert torch.equal(out, full[123:423])
+    inpl = d[0].clone()
+    _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(inpl), _hip.ptr(packed), _hip.ptr(d[6]), _hip.ptr(inpl), 700, C, hid, 1e-6, _hip.BF16, _st()))
+    assert torch.equal(inpl, full)
+
+
+def test_mlp_fused_unsupported_shapes_are_refused(hip_lib):
+    assert hip_lib.mvit_mlp_fused_pack_bytes(768, 3072) == 0 and hip_lib.mvit_mlp_fused_pack_bytes(384, 1024) == 0
+    x = torch.zeros(8, 768, device=DEV)
+    rc = hip_lib.mvit_mlp_fused_fwd(_hip.ptr(x), _hip.ptr(x), _hip.ptr(x), _hip.ptr(x), 8, 768, 3072, 1e-6, _hip.BF16, _st())
+    assert rc == -4
+    rc = hip_lib.mvit_mlp_fused_fwd(_hip.ptr(x), _hip.ptr(x), _hip.ptr(x), _hip.ptr(x), 8, 384, 1536, 1e-6, _hip.F32, _st())
+    assert rc == -4
