@@ -36,6 +36,9 @@
 #define MF_NST 4
 #endif
 #define MF_D 5               // fragment reads in flight ahead of their MFMA
+#ifndef MF_NTOP
+#define MF_NTOP 4            // GELU units run in front of phase 1's first MFMA (under the latency of the first fragment reads behind the barrier)
+#endif
 #define MF_NFB (MF_D + 1)
 #define MF_SB __builtin_amdgcn_sched_barrier(0)
 #define MF_CLOB_ALL "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
@@ -110,8 +113,9 @@ constexpr MfUnit mf_unit(int n) {
         }
     return MfUnit{-1, -1};
 }
-template <int NP, int S0, int NS>
-constexpr int mf_unit_slot(int n) { return S0 + (n * (NS - S0)) / (NP * MF_NST); }
+// NTOP: the first NTOP units run at "slot -1": in front of the phase's first MFMA, under the LDS latency of its first fragment reads
+template <int NP, int S0, int NS, int NTOP>
+constexpr int mf_unit_slot(int n) { return n < NTOP ? -1 : S0 + ((n - NTOP) * (NS - S0)) / (NP * MF_NST - NTOP); }
 
 template <int CB, int TB>
 struct MfCfg {
@@ -126,6 +130,17 @@ struct MfCfg {
     static constexpr int XV = NXF - XACC;                   // ... and in arch VGPRs
     static constexpr int NPW = CB;                          // LDS-DMA pieces per wave and iteration
     static constexpr int NPH = 4 * TB;                      // register pairs per half chunk and lane
+    static constexpr int NB1W = (4 * C * 4 + 2047) / 2048;  // 1-KiB pieces of b1' per wave (two waves share them): 3, 2, 1
+    // prologue / epilogue staging (wave-private LDS area inside the rings): a pass moves one token block's rows x one column part
+    static constexpr int CP = (C == 384) ? 2 : 1;           // column parts per row (a full 128 x 384 fp32 tile does not fit the LDS)
+    static constexpr int SEG = 4 * C / CP;                  // bytes of a row segment per pass: 768, 768, 384
+    static constexpr int PR = SEG / 16;                     // 16-byte pieces per row segment: 48, 48, 24
+    static constexpr int RS = SEG + 16;                     // padded row pitch: rows 4 banks apart -> the lane-per-row reads / writes are conflict-free
+    static constexpr int KSP = K1S / CP;                    // k-steps per pass
+    static constexpr int ST_PITCH = (32 * RS + 255) / 256 * 256;
+    static constexpr int NI = PR / 2;                       // 1-KiB wave instructions per pass on the linear side
+    static constexpr int RPI = 192 / PR;                    // rows three such instructions advance
+    static_assert(192 % PR == 0 && NI % 3 == 0, "column pattern of the linear side repeats every three instructions");
     static constexpr int PB1 = 0, PB2 = K1S;                // stream positions behind which the two bias reads of a phase are issued
     // lgkmcnt to wait for before consuming position n = the reads younger than read(n) issued by then: the fragment reads n+1 .. n+D-1
     // (as far as the stream goes) and the bias pair of a phase when it was issued in between (none in the last iteration)
@@ -183,39 +198,58 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
     };
-    dma_chunk(0);
-    if (nch > 1) dma_chunk(1);
-    if (!is_w2 && nch > 2) dma_chunk(2);
-
-    // b1' -> LDS (fp32)
-    for (int i = tid; i < nch * 8; i += 256)
-        *reinterpret_cast<float4*>(smem + 6 * WU + 16 * i) = *reinterpret_cast<const float4*>(B1p + 4 * i);
-
     // ---- prologue: the wave's token rows, LayerNorm statistics (two-pass, fp32), Xn^T fragments ------------------------------------
-    // lane (r, h) of token block tb holds Xn[tok0 + 32 tb + r][16 ks + 8 h .. + 7] for every k-step ks
+    // lane (r, h) of token block tb holds Xn[tok0 + 32 tb + r][16 ks + 8 h .. + 7] for every k-step ks.  Read lane-per-row straight
+    // from memory every load instruction touched 32 cache lines for 32 bytes each (the prologue cost 29 k cycles of a 160 k-cycle
+    // tile); here a pass brings 32 row segments in by LDS-DMA (one instruction per row, the lanes of a segment contiguous) into a
+    // wave-private area with rows 16 bytes apart from a bank period, and the lanes read their rows from there.
     bf16x8 xv[K::XV > 0 ? K::XV : 1];
+    char* const st_area = smem + wave * K::ST_PITCH;
+    const uint32_t st_lds = lds0 + (uint32_t)wave * K::ST_PITCH;
     {
         float4 v[TB][K1S][2];
-        int64_t trow[TB];
+        const uint64_t seg_mask = (K::PR >= 64) ? ~0ull : ((1ull << K::PR) - 1ull);
+        mf_for<0, TB * K::CP>([&](auto P_) {
+            constexpr int tb = P_ / K::CP, cp = P_ % K::CP;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the previous pass's reads have left the area
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
-            int64_t t = tok0 + 32 * tb + r;
-            trow[tb] = t < M ? t : M - 1;
-        }
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-            for (int ks = 0; ks < K1S; ++ks) {
-                const float* p = X + trow[tb] * C + 16 * ks + 8 * h;
-                v[tb][ks][0] = *reinterpret_cast<const float4*>(p);
-                v[tb][ks][1] = *reinterpret_cast<const float4*>(p + 4);
+            for (int row = 0; row < 32; ++row) {
+                int64_t t = tok0 + 32 * tb + row;
+                t = t < M ? t : M - 1;
+                const char* src = reinterpret_cast<const char*>(X + t * C) + cp * K::SEG;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(st_lds + row * K::RS);
+                const uint32_t l16 = lane16;
+                asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
+                             ::"s"(dst), "v"(l16), "s"(src), "s"(seg_mask) : "memory");
             }
-        // Y^T starts at x + b2: the residual and the fc2 bias ride on the accumulators, the epilogue only stores.  The lane holds
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the issuing wave's own reads need no barrier behind its vmcnt)
+            const char* rp = st_area + r * K::RS + 32 * h;
+#pragma unroll
+            for (int ksl = 0; ksl < K::KSP; ++ksl) {
+                v[tb][cp * K::KSP + ksl][0] = *reinterpret_cast<const float4*>(rp + 64 * ksl);
+                v[tb][cp * K::KSP + ksl][1] = *reinterpret_cast<const float4*>(rp + 64 * ksl + 16);
+            }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave has read its rows: the area becomes the weight rings
+        dma_chunk(0);
+        if (is_w2) {                                  // b1' (fp32, padded to whole KiB by the packer) -> LDS, split between waves 2 and 3
+            constexpr int NB1W = K::NB1W;
+            const int nb1 = (nch * 128 + 1023) / 1024;
+#pragma unroll
+            for (int i = 0; i < NB1W; ++i) {
+                int pc = (wave & 1) * NB1W + i;
+                pc = pc < nb1 ? pc : nb1 - 1;
+                dma1(reinterpret_cast<const char*>(B1p) + 1024 * pc, __builtin_amdgcn_readfirstlane(lds_b1 + 1024u * pc));
+            }
+        }
+        if (nch > 1) dma_chunk(1);
+        if (!is_w2 && nch > 2) dma_chunk(2);
+        // Y^T starts at x: the residual rides on the accumulators (the epilogue adds b2 and stores).  The lane holds
         // channels 16 ks + 8 h + e of its token, the accumulator layout wants 32 cb + 8 g + 4 h + i: the lane keeps its e = 0..3 (h = 0) /
         // e = 4..7 (h = 1) and swaps the other four with the lane of the other half (one v_permlane32_swap per register)
         mf_for<0, K::NXF>([&](auto F) {
             constexpr int f = F, ks = f / TB, tb = f % TB, cb = ks / 2, gh = ks % 2;
-            const float4 bl = *reinterpret_cast<const float4*>(B2 + 16 * ks + 4 * h), bh = *reinterpret_cast<const float4*>(B2 + 16 * ks + 8 + 4 * h);
             const float lo[4] = {v[tb][ks][0].x, v[tb][ks][0].y, v[tb][ks][0].z, v[tb][ks][0].w};
             const float hi[4] = {v[tb][ks][1].x, v[tb][ks][1].y, v[tb][ks][1].z, v[tb][ks][1].w};
             float ge[4], go[4];
@@ -225,8 +259,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
                 ge[i] = __uint_as_float(sw[0]);          // g = 2 gh:     channels 16 ks + 4 h + i
                 go[i] = __uint_as_float(sw[1]);          // g = 2 gh + 1: channels 16 ks + 8 + 4 h + i
             }
-            const uint4 ue = make_uint4(__float_as_uint(ge[0] + bl.x), __float_as_uint(ge[1] + bl.y), __float_as_uint(ge[2] + bl.z), __float_as_uint(ge[3] + bl.w));
-            const uint4 uo = make_uint4(__float_as_uint(go[0] + bh.x), __float_as_uint(go[1] + bh.y), __float_as_uint(go[2] + bh.z), __float_as_uint(go[3] + bh.w));
+            const uint4 ue = make_uint4(__float_as_uint(ge[0]), __float_as_uint(ge[1]), __float_as_uint(ge[2]), __float_as_uint(ge[3]));
+            const uint4 uo = make_uint4(__float_as_uint(go[0]), __float_as_uint(go[1]), __float_as_uint(go[2]), __float_as_uint(go[3]));
             mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh)>(ue);
             mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh + 1)>(uo);
         });
@@ -355,14 +389,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
         }
     };
     // the units of half s that fall into slot I of a phase of NS slots starting at S0
-    auto gelu_slot = [&](f32x16 (&H)[TB], bf16x8 (&G)[TB][2], const f32x4 (&bs)[2], auto S_, auto I_, auto S0_, auto NS_) {
-        constexpr int I = I_, S0 = S0_, NS = NS_;
+    auto gelu_slot = [&](f32x16 (&H)[TB], bf16x8 (&G)[TB][2], const f32x4 (&bs)[2], auto S_, auto I_, auto S0_, auto NS_, auto NTOP_) {
+        constexpr int I = I_, S0 = S0_, NS = NS_, NTOP = NTOP_;
 #ifdef MF_ABL_NOGELU
         return;
 #endif
         mf_for<0, K::NPH * MF_NST>([&](auto N_) {
             constexpr int n = N_;
-            if constexpr (mf_unit_slot<K::NPH, S0, NS>(n) == I) {
+            if constexpr (mf_unit_slot<K::NPH, S0, NS, NTOP>(n) == I) {
                 constexpr MfUnit u = mf_unit<K::NPH>(n);
                 gelu_unit(H, G, bs, S_, MIC<u.pair>{}, MIC<u.stage>{});
             }
@@ -393,8 +427,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
     f32x4 bs0[2], bs1[2];           // b1' of the lower / upper 16 hidden units of the chunk whose GELU comes next
 
     // ---- before the loop: H(0) = W1(0) Xn^T, the GELU of its lower half ------------------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // chunk 0 (and b1') has landed; W1(1), W1(2) / W2(1) stay in flight
+    if (is_w2) asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(K::NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(2 * K::NPW) : "memory");
+    __builtin_amdgcn_s_barrier();
     {
         mf_rd4<0>(bs0[0], ab);
         mf_rd4<16>(bs0[1], ab);
@@ -449,6 +485,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
         const uint32_t abt = ab + 128u * (uint32_t)(t + 1);
         if constexpr (NEXT) {
             mf_for<0, MF_D>([&](auto N_) { frag_read(N_, u1, u2); });
+            gelu_slot(Hc, Gc, bs1, MIC<1>{}, MIC<-1>{}, MIC<0>{}, MIC<K::G1>{}, MIC<MF_NTOP>{});      // under the latency of the reads just issued
+            MF_SB;
             mf_for<0, K::G1>([&](auto I_) {
                 constexpr int I = I_, n = I / TB, tb = I % TB;
                 g1(Hn, MIC<n>{}, MIC<tb>{}, MIC<(tb == 0 ? K::wcount(n, true) : -1)>{});
@@ -458,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
                     mf_rd4<16>(bs0[1], abt);
                 }
                 if constexpr (I % DSTRIDE == DSTRIDE / 2 && I / DSTRIDE < K::NPW) dma_piece(MIC<I / DSTRIDE>{});
-                gelu_slot(Hc, Gc, bs1, MIC<1>{}, I_, MIC<0>{}, MIC<K::G1>{});
+                gelu_slot(Hc, Gc, bs1, MIC<1>{}, I_, MIC<0>{}, MIC<K::G1>{}, MIC<MF_NTOP>{});
                 MF_SB;
             });
         } else {
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
             constexpr int IS = (NEXT ? K::G1 : 0) + I;
             if constexpr (IS % DSTRIDE == DSTRIDE / 2 && IS / DSTRIDE < K::NPW) dma_piece(MIC<IS / DSTRIDE>{});
             // GELU of the lower half of chunk t+1: not in slots 0, 1 (the chain's last MFMAs are asm: nothing pads their results)
-            if constexpr (NEXT) gelu_slot(Hn, Gn, bs0, MIC<0>{}, I_, MIC<2>{}, MIC<K::G2>{});
+            if constexpr (NEXT) gelu_slot(Hn, Gn, bs0, MIC<0>{}, I_, MIC<2>{}, MIC<K::G2>{}, MIC<0>{});
             MF_SB;
         });
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bs1[0]), "+v"(bs1[1]));       // (the fragment stream has drained; this closes the two bias reads)
@@ -510,21 +548,44 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
         return;
     }
 #endif
-    // ---- epilogue: Y^T (= x + b2 + fc2(...)) -> out, fp32 ---------------------------------------------------------------------------
+    // ---- epilogue: out = Y^T + b2 (Y^T started at x), fp32 -----------------------------------------------------------------------------
+    // Stored lane-per-row a store instruction covers 32 rows x 32 bytes; instead a pass writes its accumulators into the wave's
+    // staging area (padded rows: conflict-free), reads them back in memory order and stores whole 1-KiB runs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped LDS-DMA pieces of the last iterations)
+    __builtin_amdgcn_s_barrier();                          // every wave is done with the rings
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    mf_for<0, TB>([&](auto TB_) {
-        constexpr int tb = TB_;
-        const int64_t t = tok0 + 32 * tb + r;
-        if (t < M) {
-            float* orow = Out + t * C + 4 * h;
-            mf_for<0, CB * 4>([&](auto Q_) {
-                constexpr int cb = Q_ / 4, g = Q_ % 4;
+    {
+        int row_c[3], col_c[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int q = 64 * c + lane;
+            row_c[c] = q / K::PR;
+            col_c[c] = q - row_c[c] * K::PR;
+        }
+        mf_for<0, TB * K::CP>([&](auto P_) {
+            constexpr int tb = P_ / K::CP, cp = P_ % K::CP, NCB = CB / K::CP;
+            char* wp = st_area + r * K::RS + 16 * h;
+            mf_for<0, NCB * 4>([&](auto Q_) {
+                constexpr int cbl = Q_ / 4, g = Q_ % 4, cb = cp * NCB + cbl;
                 float4 a;
                 mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-                *reinterpret_cast<float4*>(orow + 32 * cb + 8 * g) = a;
+                *reinterpret_cast<float4*>(wp + (32 * cbl + 8 * g) * 4) = a;
             });
-        }
-    });
+            float4 bb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bb[c] = *reinterpret_cast<const float4*>(B2 + cp * (C / K::CP) + 4 * col_c[c]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mf_for<0, K::NI>([&](auto I_) {
+                constexpr int i = I_, c = i % 3;
+                const int row = row_c[c] + (i / 3) * K::RPI;
+                float4 a = *reinterpret_cast<const float4*>(st_area + row * K::RS + 16 * col_c[c]);
+                a.x += bb[c].x; a.y += bb[c].y; a.z += bb[c].z; a.w += bb[c].w;
+                const int64_t t = tok0 + 32 * tb + row;
+                if (t < M) *reinterpret_cast<float4*>(Out + t * C + cp * (C / K::CP) + 4 * col_c[c]) = a;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads have left the area before the next pass writes it
+        });
+    }
 }
 
 // ---- weight packing ---------------------------------------------------------------------------------------------------------
@@ -580,7 +641,7 @@ static bool mf_shape_ok(int C, int hidden) { return (C == 96 || C == 192 || C ==
 
 extern "C" int64_t mvit_mlp_fused_pack_bytes(int C, int hidden) {
     if (!mf_shape_ok(C, hidden)) return 0;
-    return (int64_t)(hidden / 32) * 128 * C + 4ll * hidden;
+    return (int64_t)(hidden / 32) * 128 * C + (4ll * hidden + 1023) / 1024 * 1024;      // b1' padded to whole KiB (it is brought in by 1-KiB LDS-DMA pieces)
 }
 
 extern "C" int mvit_mlp_fused_pack(const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2, void* packed,
@@ -600,9 +661,8 @@ extern "C" int mvit_mlp_fused_pack(const float* w1, const float* b1, const float
 template <int CB, int TB>
 static int mf_launch(const float* x, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st) {
     using K = MfCfg<CB, TB>;
-    constexpr int SMEM = 6 * K::WU + 16 * 1024;           // rings + b1' (hidden <= 1536 -> 6 KiB; the rest is slack for nothing)
-    const int smem = 6 * K::WU + 4 * hidden;
-    (void)SMEM;
+    const int ring = 6 * K::WU + (4 * hidden + 1023) / 1024 * 1024, stage = 4 * K::ST_PITCH;       // rings + b1' | the prologue's / epilogue's staging areas
+    const int smem = ring > stage ? ring : stage;
     static DevFlags attr_tab;
     bool& attr_done = dev_flag(attr_tab);
     if (!attr_done) {

@@ -495,7 +495,7 @@ def _mlp_fused_case(L, half, M, C, seed, wscale=0.05):
     ref_mlp = F.linear(F.gelu(F.linear(F.layer_norm(x, (C,), gam, bet, 1e-6), w1, b1)), w2, b2)
     d = [t.to(DEV) for t in (x, gam, bet, w1, b1, w2, b2)]
     nb = L.mvit_mlp_fused_pack_bytes(C, hid)
-    assert nb == (hid // 32) * 128 * C + 4 * hid
+    assert nb == (hid // 32) * 128 * C + (4 * hid + 1023) // 1024 * 1024
     packed = torch.empty(nb, dtype=torch.uint8, device=DEV)
     _hip.check(L.mvit_mlp_fused_pack(_hip.ptr(d[3]), _hip.ptr(d[4]), _hip.ptr(d[1]), _hip.ptr(d[2]), _hip.ptr(d[5]), _hip.ptr(packed), C, hid, _st()))
     out = torch.full((M, C), float("nan"), device=DEV)
