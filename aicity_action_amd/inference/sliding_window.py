@@ -94,6 +94,9 @@ class SlidingWindowClassifier(object):
             keep[1:] = sid[1:] != sid[:-1]                 # drop the padding duplicates
             probs = probs[order][keep]
         probs = probs.cpu().numpy()
+        core = self.model.module if hasattr(self.model, "module") else self.model
+        if hasattr(core, "check_finite"):
+            core.check_finite()                # (the copy above has synchronised: no extra wait) fp16 overflow under HIP.PRECISION auto raises here
         out = [(t0, t1, probs[k].astype(np.float32)) for k, (t0, t1) in enumerate(windows)]
         out.sort(key=lambda x: x[0])
         return out

@@ -299,10 +299,39 @@ class MViT(nn.Module):
             # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
             return forward_with_grad(self, x, return_logits)
+        self._raise_if_flagged(block=False)                 # the previous call's output, if its check has completed by now
         ns = min(self.eval_streams, x.shape[0] // 2)        # at least two clips per sub-batch
-        if ns > 1:
-            return self._forward_streams(x, return_logits, ns)
-        return self._forward_hip(x, return_logits)
+        out = self._forward_streams(x, return_logits, ns) if ns > 1 else self._forward_hip(x, return_logits)
+        hip = getattr(self.cfg, "HIP", None)
+        if self.precision == "fp16" and (getattr(hip, "PRECISION", "auto") if hip is not None else "auto") == "auto":
+            self._flag_output(out[0] if return_logits else out)
+        return out
+
+    # ---- non-finite guard of the default inference arithmetic ------------------------------------------------------------
+    # HIP.PRECISION "auto" runs inference in IEEE half (the build that meets the 1e-3 logit gate) for ANY checkpoint a user loads,
+    # and half has a finite range (65504): activations of a trained model far outside the range seen at random initialisation
+    # would overflow silently.  Every eval forward therefore leaves ONE device scalar (the sum of its output: non-finite iff any
+    # element is) and an event; the flag is read without blocking at the next forward and, blocking, by check_finite() -- which
+    # the sliding-window classifier calls where it synchronises anyway.  No host sync is added to the forward itself.
+    def _flag_output(self, out):
+        ev = torch.cuda.Event()
+        flag = out.float().sum()
+        ev.record()
+        self._finite_guard = (flag, ev)
+
+    def _raise_if_flagged(self, block):
+        g = getattr(self, "_finite_guard", None)
+        if g is None or (not block and not g[1].query()):
+            return
+        self._finite_guard = None
+        if not bool(torch.isfinite(g[0]).item()):
+            raise FloatingPointError(
+                "MViT (HIP path): non-finite output from the fp16 inference arithmetic that HIP.PRECISION 'auto' selects "
+                "(IEEE half overflows beyond 65504). Set HIP.PRECISION bf16 (or fp32) for this checkpoint.")
+
+    def check_finite(self):
+        """Blocking form of the guard: raises FloatingPointError if the last eval forward under HIP.PRECISION auto produced a non-finite output."""
+        self._raise_if_flagged(block=True)
 
     @property
     def eval_streams(self):

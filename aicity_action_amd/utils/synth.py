@@ -57,3 +57,18 @@ def synth_clip(batch, frames, size, seed=1, channels=3):
     """[B,3,T,S,S] fp32 ~ N(0,1): the normalised-pixel domain the model sees ((x/255-.45)/.225)."""
     g = np.random.Generator(np.random.PCG64([0xC11B, seed]))
     return torch.from_numpy(g.standard_normal((batch, channels, frames, size, size), dtype=np.float32))
+
+
+def stress_state_dict(sd, linear_gain=4.0, qk_gain=2.5):
+    """A "trained-like" variant of a synthetic state dict: every Linear weight of the blocks and of the head x linear_gain (activations and logits of
+    O(1-10) instead of the O(0.1) of a random initialisation) and the LayerNorm gains of the pooled q and k x qk_gain (attention
+    scores x qk_gain^2: rows with a dominant key).  Used by the statistical logit gate (oracle/make_golden_gate.py and its test)."""
+    out = {}
+    for k, v in sd.items():
+        if (k.startswith("blocks.") or k == "head.projection.weight") and k.endswith(".weight") and v.dim() == 2:
+            out[k] = v * linear_gain
+        elif k.endswith("attn.norm_q.weight") or k.endswith("attn.norm_k.weight"):
+            out[k] = v * qk_gain
+        else:
+            out[k] = v.clone()
+    return out

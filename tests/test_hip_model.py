@@ -168,3 +168,79 @@ def test_multi_stream_inference_matches_single_stream():
         out4 = model([clip])
     torch.cuda.synchronize()
     assert torch.equal(ref, out2) and torch.equal(ref, out4)
+
+
+def _gate_cases():
+    import json
+    import os
+    from conftest import GOLD
+    return json.load(open(os.path.join(GOLD, "gate_logits.json")))["cases"]
+
+
+def test_logit_gate_over_seeds_and_a_trained_like_model():
+    """The north-star gate (16-bit logits within 1e-3 of the reference's fp32 CPU logits) over a DISTRIBUTION of inputs, not one clip
+    per size: tests/golden/gate_logits.json (oracle/make_golden_gate.py, from the real reference) holds four more (weight seed, clip
+    seed) pairs at 224, two more at 448 and one "trained-like" full-size model (Linear weights x 4, q / k LayerNorm gains x 2.5:
+    |logit| up to 5.8, top probability 0.90).  The default inference arithmetic (HIP.PRECISION auto -> fp16) must meet 1e-3 absolute
+    on the BASELINE-initialised models and 1e-3 relative to the largest logit on the stressed one; bf16 is reported beside it."""
+    import os
+    from conftest import ROOT
+    from aicity_action_amd.config import load_config
+    from aicity_action_amd.utils.synth import stress_state_dict
+    worst = {"fp16": 0.0, "bf16": 0.0}
+    rows = []
+    for c in _gate_cases():
+        ref = np.array(c["logits"], np.float32).reshape(1, -1)
+        clip = synth_clip(1, c["num_frames"], c["crop"], c["clip_seed"]).cuda()
+        errs = {}
+        for prec in ("auto", "bf16"):
+            cfg = load_config(os.path.join(ROOT, "configs", "Aicity", c["yaml"]), ["NUM_GPUS", 1, "HIP.PRECISION", prec])
+            model = build_model(cfg).eval()
+            load_synth_weights(model, c["weight_seed"])
+            if c["stressed"]:
+                model.load_state_dict(stress_state_dict(model.state_dict()))
+            with torch.no_grad():
+                ran = model.precision                   # ("auto" answers fp16 only with grad mode off)
+                assert ran == ("fp16" if prec == "auto" else "bf16")
+                probs, logits = model._forward_hip(clip, return_logits=True)
+            scale = max(1.0, float(np.abs(ref).max())) if c["stressed"] else 1.0
+            errs[ran] = float(np.abs(logits.float().cpu().numpy() - ref).max()) / scale
+            if prec == "auto":
+                perr = float(np.abs(probs.float().cpu().numpy() - np.array(c["probs"], np.float32).reshape(1, -1)).max())
+            del model
+        rows.append((c["crop"], c["weight_seed"], c["clip_seed"], c["stressed"], errs["fp16"], errs["bf16"], perr))
+        for k in worst:
+            worst[k] = max(worst[k], errs[k])
+    print("\n crop  wseed cseed stressed   fp16 logit err   bf16 logit err   fp16 prob err   (stressed: relative to max |logit|)")
+    for r_ in rows:
+        print(" %4d  %5d %5d %8s   %.3e        %.3e        %.3e" % r_)
+    print("worst fp16 %.3e (gate 1e-3)   worst bf16 %.3e (reported: bf16 storage cannot meet the gate)" % (worst["fp16"], worst["bf16"]))
+    assert worst["fp16"] <= 1e-3
+
+
+def test_fp16_auto_inference_raises_on_non_finite_output():
+    """HIP.PRECISION auto picks IEEE half for any checkpoint; half overflows beyond 65504.  A model whose activations leave that range
+    must not return NaN probabilities silently: the deferred guard raises (at check_finite(), or at the next forward), with the hint
+    to pin bf16 -- and the same weights run finite in bf16."""
+    z, meta = load_golden("tiny_even")
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    outs = {}
+    for prec in ("auto", "bf16"):
+        cfg = cfg_for_case(meta, prec)
+        cfg.NUM_GPUS = 1
+        model = build_model(cfg).eval()
+        load_synth_weights(model, meta["weight_seed"])
+        with torch.no_grad():
+            model.blocks[1].mlp.fc2.weight.mul_(3.0e5)          # the block output leaves the half range (~1e5), bf16 carries it
+            p = model([clip])
+            outs[prec] = p
+            if prec == "auto":
+                with pytest.raises(FloatingPointError, match="HIP.PRECISION bf16"):
+                    model.check_finite()
+                model([clip])                                   # flagged again ...
+                torch.cuda.synchronize()
+                with pytest.raises(FloatingPointError):         # ... and raised by the next forward without an explicit check
+                    model([clip])
+            else:
+                model.check_finite()
+    assert not torch.isfinite(outs["auto"]).all() and torch.isfinite(outs["bf16"]).all()

@@ -96,3 +96,30 @@ def test_oracle_full224_train_step_matches_reference_golden():
         gref = z["grad." + k]
         assert np.abs(got - gref).max() <= 1e-5 * max(1.0, np.abs(gref).max()) + 1e-7, k
         assert abs(float(g.double().norm()) - l2) <= 1e-5 * max(l2, 1e-3), k
+
+
+def test_oracle_matches_the_reference_logits_of_the_statistical_gate_cases():
+    """tests/golden/gate_logits.json (oracle/make_golden_gate.py: the real reference's logits for further (weight seed, clip seed) pairs
+    and the trained-like stressed model): the CPU restatement reproduces them anywhere.  The 224 cases only (a 448 forward takes ~10 s
+    of CPU each; those two are covered on the GPU side and at generation time)."""
+    import json
+    import os
+    from conftest import GOLD, ROOT
+    from aicity_action_amd.config import load_config
+    from aicity_action_amd.models.mvit import MViT
+    from aicity_action_amd.utils.synth import stress_state_dict
+    cases = json.load(open(os.path.join(GOLD, "gate_logits.json")))["cases"]
+    done = 0
+    for c in cases:
+        if c["crop"] != 224 or (not c["stressed"] and done >= 2):
+            continue
+        cfg = load_config(os.path.join(ROOT, "configs", "Aicity", c["yaml"]), ["NUM_GPUS", 0])
+        mv = copy.deepcopy(cfg.MVIT.to_dict())
+        sd = synth_state_dict({k: v.shape for k, v in MViT(cfg).state_dict().items()}, c["weight_seed"])
+        if c["stressed"]:
+            sd = stress_state_dict(sd)
+        with torch.no_grad():
+            _, lg = O.forward(sd, synth_clip(1, c["num_frames"], 224, c["clip_seed"]), mv)
+        ref = np.array(c["logits"], np.float32)
+        assert np.abs(lg.numpy().reshape(-1) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        done += 0 if c["stressed"] else 1
