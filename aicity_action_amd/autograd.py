@@ -321,8 +321,7 @@ class _BlockFn(torch.autograd.Function):
         o = torch.empty(Mq, Cout, dtype=adt, device=dev)
         lse = torch.empty(B, h, Lq, dtype=torch.float32, device=dev)
         addq = 1 if hx.m.use_query_residual_pool else 0
-        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5,
-                                        addq, act, _st()), "attention")
+        _hip.check(_hip.attention_fwd(L, q, k, v, o, lse, B, h, Lq, Lk, 96 ** -0.5, addq, act, _st()), "attention")
         r = x2
         r_full = None
         if _skip_fused(g, act, B):

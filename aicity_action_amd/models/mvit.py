@@ -499,8 +499,8 @@ class MViT(nn.Module):
         del qkv
         # 4. fused attention (+ pooled-q residual), heads merged on store   attention.py:267-279
         o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
-        _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), None, B, h, Lq, Lk,
-                                        96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st), "attention")
+        _hip.check(_hip.attention_fwd(L, q, k, v, o, None, B, h, Lq, Lk, 96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st),
+                   "attention")
         if taps is not None:
             taps["block%d.q" % g.index] = q
             taps["block%d.k" % g.index] = k

@@ -101,6 +101,14 @@ int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float
  * lse: NULL, or fp32 [B][heads][Lq] receiving log2(sum_k exp(score)) (saved for the backward pass). */
 int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
+/* The same with a caller-provided workspace (>= mvit_attention_fwd_workspace_bytes; 0 = none needed for this shape): when Lq is not a
+ * multiple of 256 the ragged last query tile of every (batch, head) is computed key-split over 8 workgroups and merged, so the main
+ * grid is whole tiles only (stage 3 @448, B = 8: 768 workgroups = 3 rounds of the chip instead of 3.125).  Which rows are split
+ * depends on Lq alone, never on B: a row's result is the same in every batch it appears in.  workspace NULL = mvit_attention_fwd. */
+int64_t mvit_attention_fwd_workspace_bytes(int B, int heads, int Lq, int Lk, int act_dtype);
+int mvit_attention_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
+                          int Lq, int Lk, float scale, int add_q, int act_dtype, float* workspace, int64_t workspace_bytes,
+                          void* stream);
 
 /* Skip-path MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) on the token grid (slowfast/models/attention.py:
  * 316-318,389-395,427-432); x fp32 [B][T*H*W][C] -> y fp32 [B][T*Ho*Wo][C]. */

@@ -546,3 +546,58 @@ def test_mlp_fused_unsupported_shapes_are_refused(hip_lib):
     assert rc == -4
     rc = hip_lib.mvit_mlp_fused_fwd(_hip.ptr(x), _hip.ptr(x), _hip.ptr(x), _hip.ptr(x), 8, 384, 1536, 1e-6, _hip.F32, _st())
     assert rc == -4
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(2, 2, 256 + 128, 512, 1), (1, 4, 6272, 1568, 1), (1, 2, 512 + 33, 1568 + 40, 0), (3, 1, 300, 8 * 64, 1)])
+def test_attention_key_split_of_the_ragged_query_tile(half, B, h, Lq, Lk, add_q):
+    """mvit_attention_fwd_ws (include/mvit_hip.h): when Lq is not a multiple of 256 the last query tile of every (batch, head) runs
+    key-split over 8 workgroups + a merge.  Checked against fp32 torch: the output and the saved lse of ALL rows (split tile and
+    whole tiles), with dominant keys planted for rows of the split tile in the first, a middle and the last key range (parts whose
+    reference points differ by 2^40 must merge correctly); the unsplit entry point agrees to rounding; and the rows of one
+    (batch, head) are bit-identical whether it is launched alone or inside a larger batch (attention.py:267-279)."""
+    L = _hip.lib(half)
+    dt = torch.bfloat16 if half == "bf16" else torch.float16
+    q = _rnd(B, h, Lq, 96, seed=51)
+    k = _rnd(B, h, Lk, 96, seed=52)
+    v = _rnd(B, h, Lk, 96, seed=53)
+    t0 = (Lq // 256) * 256
+    for qi, kj, c in [(t0 + 1, 3, 3.0), (t0 + 2, Lk // 2, 2.5), (Lq - 1, Lk - 1, 3.0), (t0 + 5, Lk - 70, 0.5), (7, Lk - 3, 2.0)]:
+        k[:, :, kj] = q[:, :, qi] * c
+    q, k, v = (t.to(dt) for t in (q, k, v))
+    scale = 96 ** -0.5
+    s = (q.float() @ k.float().transpose(-2, -1)) * scale
+    ref = s.softmax(-1) @ v.float()
+    if add_q:
+        ref = ref + q.float()
+    ref = ref.transpose(1, 2).reshape(B, Lq, h * 96)
+    ref_lse = torch.logsumexp(s, -1) * 1.4426950408889634
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    nb = L.mvit_attention_fwd_workspace_bytes(B, h, Lq, Lk, _hip.BF16)
+    assert nb == B * h * 8 * 256 * 98 * 4
+    ws = torch.full((nb // 4,), float("nan"), device=DEV)
+    out = torch.full((B, Lq, h * 96), float("nan"), dtype=dt, device=DEV)
+    lse = torch.full((B, h, Lq), float("nan"), device=DEV)
+    _hip.check(L.mvit_attention_fwd_ws(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk, scale, add_q,
+                                       _hip.BF16, _hip.ptr(ws), nb, _st()))
+    tol = 1e-2 if half == "bf16" else 2e-3
+    _close(out, ref, tol)
+    bound = 2e-3 + (s.abs().amax(-1) * 1.4426950408889634) * 2.0 ** (-9 if half == "bf16" else -11)
+    err = (lse.cpu() - ref_lse).abs()
+    assert bool((err <= bound).all()), "lse err %.3e" % err.max().item()
+    out0 = torch.empty_like(out)
+    _hip.check(L.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out0), None, B, h, Lq, Lk, scale, add_q, _hip.BF16, _st()))
+    assert torch.equal(out0[:, :t0], out[:, :t0])                    # whole tiles: the same kernel, the same bits
+    _close(out[:, t0:], out0[:, t0:].float().cpu(), tol)
+    # one (batch, head) group alone: bit-identical rows
+    q1, k1, v1 = qd[:1].contiguous(), kd[:1].contiguous(), vd[:1].contiguous()
+    nb1 = L.mvit_attention_fwd_workspace_bytes(1, h, Lq, Lk, _hip.BF16)
+    ws1 = torch.empty(nb1 // 4, device=DEV)
+    out1 = torch.empty(1, Lq, h * 96, dtype=dt, device=DEV)
+    _hip.check(L.mvit_attention_fwd_ws(_hip.ptr(q1), _hip.ptr(k1), _hip.ptr(v1), _hip.ptr(out1), None, 1, h, Lq, Lk, scale, add_q, _hip.BF16,
+                                       _hip.ptr(ws1), nb1, _st()))
+    assert torch.equal(out1[0], out[0])
+    # too small a workspace is refused; shapes without a ragged tile need none
+    assert L.mvit_attention_fwd_ws(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), None, B, h, Lq, Lk, scale, add_q, _hip.BF16,
+                                   _hip.ptr(ws), nb - 4, _st()) == -1
+    assert L.mvit_attention_fwd_workspace_bytes(B, h, 512, Lk, _hip.BF16) == 0 and L.mvit_attention_fwd_workspace_bytes(B, h, Lq, 448, _hip.BF16) == 0
