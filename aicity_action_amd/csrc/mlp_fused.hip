@@ -70,6 +70,14 @@ template <int YR, int W> __device__ __forceinline__ void mf_g2(bf16x8& w, const 
     if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%c4)\n\t" MF_MFMA "a[%c2:%c3], %0, %1, a[%c2:%c3]" : "+v"(w) : "v"(g), "i"(YR), "i"(YR + 15), "i"(W));
     else asm volatile(MF_MFMA "a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(g), "i"(YR), "i"(YR + 15));
 }
+template <int YR, int XR, int W> __device__ __forceinline__ void mf_p1a(bf16x8& w) {        // a[YR:YR+15] += w . X (X fragment in a[XR:XR+3])
+    if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%c5)\n\t" MF_MFMA "a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" : "+v"(w) : "i"(YR), "i"(YR + 15), "i"(XR), "i"(XR + 3), "i"(W));
+    else asm volatile(MF_MFMA "a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" ::"v"(w), "i"(YR), "i"(YR + 15), "i"(XR), "i"(XR + 3));
+}
+template <int YR, int W> __device__ __forceinline__ void mf_p1v(bf16x8& w, const bf16x8& x) {   // a[YR:YR+15] += w . x (x in arch VGPRs)
+    if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%c4)\n\t" MF_MFMA "a[%c2:%c3], %0, %1, a[%c2:%c3]" : "+v"(w) : "v"(x), "i"(YR), "i"(YR + 15), "i"(W));
+    else asm volatile(MF_MFMA "a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(x), "i"(YR), "i"(YR + 15));
+}
 template <int OFF> __device__ __forceinline__ void mf_rd(bf16x8& f, uint32_t addr) {
 #ifdef MF_ABL_NORD
     asm volatile("" : "+v"(f) : "v"(addr));
@@ -130,7 +138,8 @@ struct MfCfg {
     static constexpr int XV = NXF - XACC;                   // ... and in arch VGPRs
     static constexpr int NPW = CB;                          // LDS-DMA pieces per wave and iteration
     static constexpr int NPH = 4 * TB;                      // register pairs per half chunk and lane
-    static constexpr int NB1W = (4 * C * 4 + 2047) / 2048;  // 1-KiB pieces of b1' per wave (two waves share them): 3, 2, 1
+    static constexpr int B1BYTES = (16 * C + 1023) / 1024 * 1024;     // b1' (fp32 [4C]) padded to whole KiB
+    static constexpr int BPBYTES = (4 * C + 1023) / 1024 * 1024;      // proj bias (fp32 [C]) padded likewise (PROJ form)
     // prologue / epilogue staging (wave-private LDS area inside the rings): a pass moves one token block's rows x one column part
     static constexpr int CP = (C == 384) ? 2 : 1;           // column parts per row (a full 128 x 384 fp32 tile does not fit the LDS)
     static constexpr int SEG = 4 * C / CP;                  // bytes of a row segment per pass: 768, 768, 384
@@ -157,10 +166,17 @@ struct MfCfg {
     static_assert(L % MF_NFB == 0, "fragment ring");
 };
 
-template <int CB, int TB>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restrict__ X, const char* __restrict__ Wpk, const float* __restrict__ B1p,
-                                                           const float* __restrict__ B2, float* __restrict__ Out, int64_t M, int nch, float eps) {
+// PROJ: the attention output projection rides along (attention.py:281,434: y = r + proj(o), then the block tail on y): X is the
+// residual r, Oa the attention output (16 bit); Y^T starts at r, the proj product accumulates straight onto those accumulators (same
+// W1-format chunk images, streamed through the W1 ring in front of the MLP's), + proj bias, and LayerNorm is taken FROM the
+// accumulators.  y never reaches HBM and the proj launch (HBM-bound: 193 MB for 15 us of MFMA at stage 3) disappears.
+template <int CB, int TB, bool PROJ>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restrict__ X, const bf16_t* __restrict__ Oa, const char* __restrict__ Wpk,
+                                                           const float* __restrict__ B1p, const float* __restrict__ B2, float* __restrict__ Out,
+                                                           int64_t M, int nch, float eps) {
     using K = MfCfg<CB, TB>;
+    constexpr int NPC = CB;                               // proj chunks (32 output channels each)
+    const char* const Wmlp = Wpk + (PROJ ? NPC * K::WU : 0);
     constexpr int C = K::C, K1S = K::K1S, WU = K::WU;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MF_STAMP
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
 
     // ---- LDS-DMA: waves 0, 1 move W1 chunk images, waves 2, 3 W2 chunk images; a piece is a linear 1-KiB copy ---------------------
     const bool is_w2 = wave >= 2;
-    const char* src_role = Wpk + (is_w2 ? WU : 0) + 1024 * (K::NPW * (wave & 1));
+    const char* src_role = Wmlp + (is_w2 ? WU : 0) + 1024 * (K::NPW * (wave & 1));
     const uint32_t dst_role = (is_w2 ? lds_w2 : lds_w1) + 1024 * (K::NPW * (wave & 1));
     uint32_t lane16 = 16u * lane;           // (not const: a generic lambda must capture it for its asm operand)
     auto dma1 = [&](const char* base, uint32_t lds) {
@@ -197,6 +213,26 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
         const uint32_t d = __builtin_amdgcn_readfirstlane(dst_role + (uint32_t)(chunk % 3) * WU);
 #pragma unroll
         for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
+    };
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
+    // W1 image: slab q (k 64q .. 64q+63) = 32 rows x 128 B, 16-byte piece (2 (ks % 4) + h) of row r at position piece ^ ((r >> 1) & 7);
+    //           C = 96 ends in a half slab (k 64 .. 95) of 32 rows x 64 B, piece (2 (ks % 4) + h) at position piece ^ ((r >> 2) & 3)
+    // W2 image: row ch x 64 B, piece (2 s + h) at position piece ^ ((ch >> 2) & 3)
+    uint32_t a1[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a1[j] = lds_w1 + r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a2[s] = lds_w2 + r * 64 + (((2 * s + h) ^ ((r >> 2) & 3)) << 4);
+    constexpr int NFS = C / 64;                  // full slabs; the half slab's lane addresses are those of the W2 image's rows
+    const uint32_t ab = lds_b1 + 32 * h;             // bias piece (chunk c, half s, quarter q): + 128 c + 64 s + 16 q
+
+    bf16x8 wf[MF_NFB];
+    // stream position n of an iteration: n < K1S -> W1 fragment of k-step n (chunk unit u1), else W2 fragment j = n - K1S = s CB + cb (unit u2)
+    auto frag_read = [&](auto N_, uint32_t u1, uint32_t u2) {
+        constexpr int n = N_;
+        if constexpr (n < 4 * NFS) mf_rd<(n / 4) * 4096>(wf[n % MF_NFB], a1[n % 4] + u1);
+        else if constexpr (n < K1S) mf_rd<NFS * 4096>(wf[n % MF_NFB], a2[n % 4] - 3 * WU + u1);
+        else mf_rd<((n - K1S) % CB) * 2048>(wf[n % MF_NFB], a2[(n - K1S) / CB] + u2);
     };
     // ---- prologue: the wave's token rows, LayerNorm statistics (two-pass, fp32), Xn^T fragments ------------------------------------
     // lane (r, h) of token block tb holds Xn[tok0 + 32 tb + r][16 ks + 8 h .. + 7] for every k-step ks.  Read lane-per-row straight
@@ -230,21 +266,61 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
                 v[tb][cp * K::KSP + ksl][1] = *reinterpret_cast<const float4*>(rp + 64 * ksl + 16);
             }
         });
+        if constexpr (PROJ) {        // the attention output rows (16 bit): one more pass per token block, straight into the fragment registers
+            constexpr int RSO = 2 * C + 16, PRO = C / 8;
+            const uint64_t o_mask = (1ull << PRO) - 1ull;
+            mf_for<0, TB>([&](auto T_) {
+                constexpr int tb = T_;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int row = 0; row < 32; ++row) {
+                    int64_t t = tok0 + 32 * tb + row;
+                    t = t < M ? t : M - 1;
+                    const char* src = reinterpret_cast<const char*>(Oa + t * C);
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(st_lds + row * RSO);
+                    const uint32_t l16 = lane16;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1"
+                                 ::"s"(dst), "v"(l16), "s"(src), "s"(o_mask) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char* rp = st_area + r * RSO + 16 * h;
+                mf_for<0, K1S>([&](auto KS_) {
+                    constexpr int ks = KS_, f = ks * TB + tb;
+                    const uint4 u = *reinterpret_cast<const uint4*>(rp + 32 * ks);
+                    if constexpr (f < K::XACC) mf_aput<K::YREG + 4 * f>(u);
+                    else {
+                        xv[f - K::XACC] = *reinterpret_cast<const bf16x8*>(&u);
+                        asm volatile("" : "+v"(xv[f - K::XACC]));
+                    }
+                });
+            });
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // every wave has read its rows: the area becomes the weight rings
-        dma_chunk(0);
-        if (is_w2) {                                  // b1' (fp32, padded to whole KiB by the packer) -> LDS, split between waves 2 and 3
-            constexpr int NB1W = K::NB1W;
-            const int nb1 = (nch * 128 + 1023) / 1024;
+        if constexpr (PROJ) {
+            if (!is_w2) {                             // the W1-format stream S = [proj chunks | MLP chunks]: S[0], S[1]
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const char* b = Wpk + 1024 * (K::NPW * (wave & 1)) + c * WU;
+                    const uint32_t d = __builtin_amdgcn_readfirstlane(dst_role + (uint32_t)c * WU);
+#pragma unroll
+                    for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
+                }
+            } else dma_chunk(0);
+        } else dma_chunk(0);
+        if (is_w2) {                                  // b1' (and the proj bias behind it): fp32, padded to whole KiB by the packer -> LDS, waves 2 and 3
+            constexpr int NBP = (K::B1BYTES + (PROJ ? K::BPBYTES : 0)) / 1024, NB1W = (NBP + 1) / 2;
 #pragma unroll
             for (int i = 0; i < NB1W; ++i) {
                 int pc = (wave & 1) * NB1W + i;
-                pc = pc < nb1 ? pc : nb1 - 1;
+                pc = pc < NBP ? pc : NBP - 1;
                 dma1(reinterpret_cast<const char*>(B1p) + 1024 * pc, __builtin_amdgcn_readfirstlane(lds_b1 + 1024u * pc));
             }
         }
-        if (nch > 1) dma_chunk(1);
-        if (!is_w2 && nch > 2) dma_chunk(2);
+        if (!PROJ || is_w2) {
+            if (nch > 1) dma_chunk(1);
+            if (!is_w2 && nch > 2) dma_chunk(2);
+        }
         // Y^T starts at x: the residual rides on the accumulators (the epilogue adds b2 and stores).  The lane holds
         // channels 16 ks + 8 h + e of its token, the accumulator layout wants 32 cb + 8 g + 4 h + i: the lane keeps its e = 0..3 (h = 0) /
         // e = 4..7 (h = 1) and swaps the other four with the lane of the other half (one v_permlane32_swap per register)
@@ -264,38 +340,129 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
             mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh)>(ue);
             mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh + 1)>(uo);
         });
+        if constexpr (!PROJ) {
+    #pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                float s = 0.f;
+    #pragma unroll
+                for (int ks = 0; ks < K1S; ++ks)
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) s += (v[tb][ks][q].x + v[tb][ks][q].y) + (v[tb][ks][q].z + v[tb][ks][q].w);
+                s += __shfl_xor(s, 32, 64);
+                const float mean = s * (1.0f / C);
+                float qq = 0.f;
+    #pragma unroll
+                for (int ks = 0; ks < K1S; ++ks)
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float4& e = v[tb][ks][q];
+                        e.x -= mean; e.y -= mean; e.z -= mean; e.w -= mean;
+                        qq += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+                    }
+                qq += __shfl_xor(qq, 32, 64);
+                const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
+    #pragma unroll
+                for (int ks = 0; ks < K1S; ++ks)
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float4& e = v[tb][ks][q];
+                        e.x *= rstd; e.y *= rstd; e.z *= rstd; e.w *= rstd;
+                    }
+            }
+            mf_for<0, K::NXF>([&](auto F) {
+                constexpr int f = F, ks = f / TB, tb = f % TB;
+                const uint4 u = make_uint4(pack_bf16x2(v[tb][ks][0].x, v[tb][ks][0].y), pack_bf16x2(v[tb][ks][0].z, v[tb][ks][0].w),
+                                           pack_bf16x2(v[tb][ks][1].x, v[tb][ks][1].y), pack_bf16x2(v[tb][ks][1].z, v[tb][ks][1].w));
+                if constexpr (f < K::XACC) mf_aput<K::YREG + 4 * f>(u);
+                else {
+                    xv[f - K::XACC] = *reinterpret_cast<const bf16x8*>(&u);
+                    asm volatile("" : "+v"(xv[f - K::XACC]));
+                }
+            });
+        }
+    }
+    if constexpr (PROJ) {
+        // ---- y = r + proj(o) + b_proj on the accumulators: chunk p = output channels 32p .. 32p+31 = Y^T tile row p ---------------------
+        mf_for<0, NPC>([&](auto P_) {
+            constexpr int p = P_;
+            asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(K::NPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!is_w2) {                             // S[p + 2]: a proj chunk, or the W1 image of MLP chunk p + 2 - NPC
+                constexpr int i2 = p + 2;
+                const char* b = (i2 < NPC) ? Wpk + 1024 * (K::NPW * (wave & 1)) + i2 * WU : src_role + (int64_t)(i2 - NPC) * K::CHB;
+                const uint32_t d = __builtin_amdgcn_readfirstlane(dst_role + (uint32_t)(i2 % 3) * WU);
+#pragma unroll
+                for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
+            }
+            constexpr uint32_t u1 = (uint32_t)(p % 3) * WU;
+            mf_for<0, (MF_D < K1S ? MF_D : K1S)>([&](auto N_) { frag_read(N_, u1, 0u); });
+            mf_for<0, K::G1>([&](auto I_) {
+                constexpr int I = I_, n = I / TB, tb = I % TB, f = n * TB + tb;
+                constexpr int W = (tb == 0) ? ((K1S - 1 - n < MF_D - 1) ? K1S - 1 - n : MF_D - 1) : -1;
+                if constexpr (f < K::XACC) mf_p1a<16 * (p * TB + tb), K::YREG + 4 * f, W>(wf[n % MF_NFB]);
+                else mf_p1v<16 * (p * TB + tb), W>(wf[n % MF_NFB], xv[f - K::XACC]);
+                if constexpr (tb == 0 && n + MF_D < K1S) frag_read(MIC<n + MF_D>{}, u1, 0u);
+                MF_SB;
+            });
+        });
+        __builtin_amdgcn_s_barrier();                 // the last proj chunk's buffer is free: it takes the W1 image of MLP chunk 2
+        if (!is_w2) {
+            const char* b = src_role + (int64_t)2 * K::CHB;
+            const uint32_t d = __builtin_amdgcn_readfirstlane(dst_role + 2u * WU);
+#pragma unroll
+            for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");        // the last MFMAs have left the matrix pipe
+        // ---- LayerNorm from the accumulators (+ proj bias, written back: Y^T = y), fragments by the inverse of the start-value swap ----
+        float yv[TB][CB][16];
+        const char* bp = smem + 6 * WU + K::B1BYTES + 16 * h;
+        mf_for<0, TB * CB * 4>([&](auto Q_) {
+            constexpr int tb = Q_ / (CB * 4), cb = (Q_ / 4) % CB, g = Q_ % 4;
+            float4 a;
+            mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+            const float4 bb = *reinterpret_cast<const float4*>(bp + (32 * cb + 8 * g) * 4);
+            a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+            const uint4 u = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+            mf_aput<16 * (cb * TB + tb) + 4 * g>(u);
+            yv[tb][cb][4 * g] = a.x; yv[tb][cb][4 * g + 1] = a.y; yv[tb][cb][4 * g + 2] = a.z; yv[tb][cb][4 * g + 3] = a.w;
+        });
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) {
             float s = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < K1S; ++ks)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) s += (v[tb][ks][q].x + v[tb][ks][q].y) + (v[tb][ks][q].z + v[tb][ks][q].w);
+                for (int i = 0; i < 16; i += 4) s += (yv[tb][cb][i] + yv[tb][cb][i + 1]) + (yv[tb][cb][i + 2] + yv[tb][cb][i + 3]);
             s += __shfl_xor(s, 32, 64);
             const float mean = s * (1.0f / C);
             float qq = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < K1S; ++ks)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float4& e = v[tb][ks][q];
-                    e.x -= mean; e.y -= mean; e.z -= mean; e.w -= mean;
-                    qq += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+                for (int i = 0; i < 16; ++i) {
+                    yv[tb][cb][i] -= mean;
+                    qq = fmaf(yv[tb][cb][i], yv[tb][cb][i], qq);
                 }
             qq += __shfl_xor(qq, 32, 64);
             const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
 #pragma unroll
-            for (int ks = 0; ks < K1S; ++ks)
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float4& e = v[tb][ks][q];
-                    e.x *= rstd; e.y *= rstd; e.z *= rstd; e.w *= rstd;
-                }
+                for (int i = 0; i < 16; ++i) yv[tb][cb][i] *= rstd;
         }
+        // lane (r, h) holds channels 32 cb + 8 g + 4 h + i; fragment k-step 2 cb + gh wants 32 cb + 16 gh + 8 h + e: the lane keeps
+        // g = 2 gh + h and receives the other half's registers of the same g (v_permlane32_swap of the g-even with the g-odd register)
         mf_for<0, K::NXF>([&](auto F) {
-            constexpr int f = F, ks = f / TB, tb = f % TB;
-            const uint4 u = make_uint4(pack_bf16x2(v[tb][ks][0].x, v[tb][ks][0].y), pack_bf16x2(v[tb][ks][0].z, v[tb][ks][0].w),
-                                       pack_bf16x2(v[tb][ks][1].x, v[tb][ks][1].y), pack_bf16x2(v[tb][ks][1].z, v[tb][ks][1].w));
+            constexpr int f = F, ks = f / TB, tb = f % TB, cb = ks / 2, gh = ks % 2;
+            float lo[4], hi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(yv[tb][cb][4 * (2 * gh) + i]), __float_as_uint(yv[tb][cb][4 * (2 * gh + 1) + i]),
+                                                                 false, false);
+                lo[i] = __uint_as_float(sw[0]);
+                hi[i] = __uint_as_float(sw[1]);
+            }
+            const uint4 u = make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
             if constexpr (f < K::XACC) mf_aput<K::YREG + 4 * f>(u);
             else {
                 xv[f - K::XACC] = *reinterpret_cast<const bf16x8*>(&u);
@@ -304,26 +471,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
         });
     }
 
-    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
-    // W1 image: slab q (k 64q .. 64q+63) = 32 rows x 128 B, 16-byte piece (2 (ks % 4) + h) of row r at position piece ^ ((r >> 1) & 7);
-    //           C = 96 ends in a half slab (k 64 .. 95) of 32 rows x 64 B, piece (2 (ks % 4) + h) at position piece ^ ((r >> 2) & 3)
-    // W2 image: row ch x 64 B, piece (2 s + h) at position piece ^ ((ch >> 2) & 3)
-    uint32_t a1[4], a2[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a1[j] = lds_w1 + r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) a2[s] = lds_w2 + r * 64 + (((2 * s + h) ^ ((r >> 2) & 3)) << 4);
-    constexpr int NFS = C / 64;                  // full slabs; the half slab's lane addresses are those of the W2 image's rows
-    const uint32_t ab = lds_b1 + 32 * h;             // bias piece (chunk c, half s, quarter q): + 128 c + 64 s + 16 q
-
-    bf16x8 wf[MF_NFB];
-    // stream position n of an iteration: n < K1S -> W1 fragment of k-step n (chunk unit u1), else W2 fragment j = n - K1S = s CB + cb (unit u2)
-    auto frag_read = [&](auto N_, uint32_t u1, uint32_t u2) {
-        constexpr int n = N_;
-        if constexpr (n < 4 * NFS) mf_rd<(n / 4) * 4096>(wf[n % MF_NFB], a1[n % 4] + u1);
-        else if constexpr (n < K1S) mf_rd<NFS * 4096>(wf[n % MF_NFB], a2[n % 4] - 3 * WU + u1);
-        else mf_rd<((n - K1S) % CB) * 2048>(wf[n % MF_NFB], a2[(n - K1S) / CB] + u2);
-    };
     // ---- GELU of one register pair, in stages ------------------------------------------------------------------------------------
     // pair p of a half chunk s: token block p / 4, registers 8 s + 2 (p % 4), + 1 of its H tile; result = word p % 4 of G[tb][s]
     float gx[MF_NST][2], gq[MF_NST][2], g2[MF_NST][2];
@@ -637,11 +784,43 @@ __global__ __launch_bounds__(256) void mlp_pack_bias_kernel(const float* __restr
     if (lane == 0) out[hid] = b1[hid] + s;
 }
 
+// proj chunk images (W1 format, rows in natural order: MFMA row m of chunk c = output channel 32c + m; no LayerNorm affine: the
+// operand is the attention output), one thread per 16-byte piece
+__global__ __launch_bounds__(256) void mlp_pack_proj_kernel(const float* __restrict__ Wp, char* __restrict__ out, int C) {
+    const int WU = 64 * C, npc = C / 32;
+    const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ppc = WU / 16;
+    if (piece >= (int64_t)npc * ppc) return;
+    const int c = (int)(piece / ppc), pi = (int)(piece % ppc), nfs = C / 64;
+    int m, k0;
+    if (pi < nfs * 256) {
+        const int q = pi / 256, pos = pi % 8;
+        m = (pi % 256) / 8;
+        k0 = 64 * q + 8 * (pos ^ ((m >> 1) & 7));
+    } else {
+        const int p1 = pi - nfs * 256, pos = p1 % 4;
+        m = p1 / 4;
+        k0 = 64 * nfs + 8 * (pos ^ ((m >> 2) & 3));
+    }
+    const float* src = Wp + (int64_t)(32 * c + m) * C + k0;
+    uint4 u = make_uint4(pack_bf16x2(src[0], src[1]), pack_bf16x2(src[2], src[3]), pack_bf16x2(src[4], src[5]), pack_bf16x2(src[6], src[7]));
+    *reinterpret_cast<uint4*>(out + piece * 16) = u;
+}
+__global__ __launch_bounds__(256) void mlp_copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 static bool mf_shape_ok(int C, int hidden) { return (C == 96 || C == 192 || C == 384) && hidden == 4 * C; }
+static int64_t mf_mlp_bytes(int C, int hidden) { return (int64_t)(hidden / 32) * 128 * C + (4ll * hidden + 1023) / 1024 * 1024; }
 
 extern "C" int64_t mvit_mlp_fused_pack_bytes(int C, int hidden) {
     if (!mf_shape_ok(C, hidden)) return 0;
-    return (int64_t)(hidden / 32) * 128 * C + (4ll * hidden + 1023) / 1024 * 1024;      // b1' padded to whole KiB (it is brought in by 1-KiB LDS-DMA pieces)
+    return mf_mlp_bytes(C, hidden);      // b1' padded to whole KiB (it is brought in by 1-KiB LDS-DMA pieces)
+}
+extern "C" int64_t mvit_block_tail_pack_bytes(int C, int hidden) {
+    if (!mf_shape_ok(C, hidden)) return 0;
+    return (int64_t)(C / 32) * 64 * C + mf_mlp_bytes(C, hidden) + (4ll * C + 1023) / 1024 * 1024;       // proj chunks | MLP image | proj bias
 }
 
 extern "C" int mvit_mlp_fused_pack(const float* w1, const float* b1, const float* gamma, const float* beta, const float* w2, void* packed,
@@ -657,16 +836,32 @@ extern "C" int mvit_mlp_fused_pack(const float* w1, const float* b1, const float
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
+extern "C" int mvit_block_tail_pack(const float* wproj, const float* bproj, const float* w1, const float* b1, const float* gamma,
+                                    const float* beta, const float* w2, void* packed, int C, int hidden, void* stream) {
+    if (!wproj || !bproj || !packed) return MVIT_EINVAL;
+    if (!mf_shape_ok(C, hidden)) return MVIT_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    char* base = reinterpret_cast<char*>(packed);
+    const int64_t proj_bytes = (int64_t)(C / 32) * 64 * C, pieces = proj_bytes / 16;
+    hipLaunchKernelGGL(mlp_pack_proj_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, wproj, base, C);
+    MVIT_LAUNCH_CHECK();
+    const int rc = mvit_mlp_fused_pack(w1, b1, gamma, beta, w2, base + proj_bytes, C, hidden, stream);
+    if (rc != MVIT_OK) return rc;
+    hipLaunchKernelGGL(mlp_copy_f32_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, bproj,
+                       reinterpret_cast<float*>(base + proj_bytes + mf_mlp_bytes(C, hidden)), C);
+    MVIT_LAUNCH_CHECK();
+    return MVIT_OK;
+}
 
-template <int CB, int TB>
-static int mf_launch(const float* x, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st) {
+template <int CB, int TB, bool PROJ>
+static int mf_launch(const float* x, const void* o, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st) {
     using K = MfCfg<CB, TB>;
-    const int ring = 6 * K::WU + (4 * hidden + 1023) / 1024 * 1024, stage = 4 * K::ST_PITCH;       // rings + b1' | the prologue's / epilogue's staging areas
+    const int ring = 6 * K::WU + K::B1BYTES + (PROJ ? K::BPBYTES : 0), stage = 4 * K::ST_PITCH;       // rings + biases | the prologue's / epilogue's staging areas
     const int smem = ring > stage ? ring : stage;
     static DevFlags attr_tab;
     bool& attr_done = dev_flag(attr_tab);
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<CB, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<CB, TB, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return MVIT_ELAUNCH;
         attr_done = true;
     }
@@ -674,8 +869,8 @@ static int mf_launch(const float* x, const void* packed, const float* b2, float*
     if (tiles >= (1ll << 31)) return MVIT_EUNSUPPORTED;
     const int nch = hidden / 32;
     const char* wpk = reinterpret_cast<const char*>(packed);
-    const float* b1p = reinterpret_cast<const float*>(wpk + (int64_t)nch * K::CHB);
-    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB>), dim3((unsigned)tiles), dim3(256), smem, st, x, wpk, b1p, b2, out, M, nch, eps);
+    const float* b1p = reinterpret_cast<const float*>(wpk + (PROJ ? (int64_t)CB * K::WU : 0) + (int64_t)nch * K::CHB);
+    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB, PROJ>), dim3((unsigned)tiles), dim3(256), smem, st, x, (const bf16_t*)o, wpk, b1p, b2, out, M, nch, eps);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -688,8 +883,21 @@ extern "C" int mvit_mlp_fused_fwd(const float* x, const void* packed, const floa
     if (M == 0) return MVIT_OK;
     hipStream_t st = as_stream(stream);
     switch (C) {
-        case 384: return mf_launch<12, 1>(x, packed, b2, out, M, hidden, eps, st);
-        case 192: return mf_launch<6, 2>(x, packed, b2, out, M, hidden, eps, st);
-        default: return mf_launch<3, 2>(x, packed, b2, out, M, hidden, eps, st);
+        case 384: return mf_launch<12, 1, false>(x, nullptr, packed, b2, out, M, hidden, eps, st);
+        case 192: return mf_launch<6, 2, false>(x, nullptr, packed, b2, out, M, hidden, eps, st);
+        default: return mf_launch<3, 2, false>(x, nullptr, packed, b2, out, M, hidden, eps, st);
+    }
+}
+extern "C" int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
+                                   int hidden, float eps, int act_dtype, void* stream) {
+    if (!o || !resid || !packed || !b2 || !out || M < 0) return MVIT_EINVAL;
+    if (act_dtype != MVIT_BF16) return MVIT_EUNSUPPORTED;
+    if (!mf_shape_ok(C, hidden)) return MVIT_EUNSUPPORTED;
+    if (M == 0) return MVIT_OK;
+    hipStream_t st = as_stream(stream);
+    switch (C) {
+        case 384: return mf_launch<12, 1, true>(resid, o, packed, b2, out, M, hidden, eps, st);
+        case 192: return mf_launch<6, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
+        default: return mf_launch<3, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
     }
 }

@@ -90,6 +90,8 @@ def _unsupported(cond, what):
 
 # the fused block tail (csrc/mlp_fused.hip) for the inference forward; MVIT_MLP_FUSE=0 keeps LayerNorm + fc1 + fc2 as three launches (A/B runs)
 _MLP_FUSE = os.environ.get("MVIT_MLP_FUSE", "1") != "0"
+# ... with the attention output projection in front of it (mvit_block_tail_fwd); MVIT_TAIL_FUSE=0 keeps proj as its own launch
+_TAIL_FUSE = os.environ.get("MVIT_TAIL_FUSE", "1") != "0"
 
 
 @MODEL_REGISTRY.register()
@@ -353,7 +355,9 @@ class MViT(nn.Module):
         act = _hip.F32 if self.precision == "fp32" else _hip.BF16
         fused = set()
         for blk in self.blocks:                    # packed block-tail weights: built once, on the caller's stream
-            if self._mlp_packed(blk, act) is not None:
+            if self._tail_packed(blk, act) is not None:
+                fused.update((id(blk.mlp.fc1), id(blk.mlp.fc2), id(blk.attn.proj)))
+            elif self._mlp_packed(blk, act) is not None:
                 fused.update((id(blk.mlp.fc1), id(blk.mlp.fc2)))
         for m in self.modules():                   # 16-bit weight copies are built once, on the caller's stream
             if isinstance(m, nn.Linear) and m.weight.is_cuda and id(m) not in fused:
@@ -417,6 +421,28 @@ class MViT(nn.Module):
         if self.training and not self.use_act_in_train:
             return logits
         return probs
+
+    def _tail_packed(self, blk, act, prec=None):
+        """proj + norm2 + fc1 + fc2 in the layout of mvit_block_tail_fwd (the fused block tail with the attention output projection in
+        front), cached per weight version; None where it does not apply (see _mlp_packed; MVIT_TAIL_FUSE=0)."""
+        if act == _hip.F32 or not (_MLP_FUSE and _TAIL_FUSE):
+            return None
+        fc1, fc2, n2, pj = blk.mlp.fc1, blk.mlp.fc2, blk.norm2, blk.attn.proj
+        hid, C = fc1.weight.shape
+        if C not in (96, 192, 384) or hid != 4 * C or fc1.bias is None or fc2.bias is None or pj.bias is None or tuple(pj.weight.shape) != (C, C):
+            return None
+        prec = prec or self.precision
+        src = (pj.weight, pj.bias, fc1.weight, fc1.bias, n2.weight, n2.bias, fc2.weight)
+        ver = tuple((t._version, t.data_ptr()) for t in src)
+        key = ("tail", prec, id(blk))
+        ent = self._bf16_cache.get(key)
+        if ent is None or ent[0] != ver:
+            Lb = self._lib(prec)
+            buf = torch.empty(Lb.mvit_block_tail_pack_bytes(C, hid), dtype=torch.uint8, device=fc1.weight.device)
+            _hip.check(Lb.mvit_block_tail_pack(*[_hip.ptr(t) for t in src], _hip.ptr(buf), C, hid, torch.cuda.current_stream().cuda_stream), "tail_pack")
+            ent = (ver, buf)
+            self._bf16_cache[key] = ent
+        return ent[1]
 
     def _mlp_packed(self, blk, act, prec=None):
         """The block's norm2 / fc1 / fc2 weights in the layout of the fused block-tail kernel (mvit_mlp_fused_pack: 16-bit chunk images,
@@ -522,6 +548,13 @@ class MViT(nn.Module):
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r), _hip.ptr(rp), B, T, H, W, Cout, st), "maxpool")
             r = rp
+        # 6-9 in one kernel where the widths allow: y = r + proj(o) stays in the accumulators, x_out = y + mlp(LN2(y))   attention.py:281,434-445
+        tk = self._tail_packed(blk, act)
+        if tk is not None:
+            out = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o), _hip.ptr(r), _hip.ptr(tk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out), B * Lq, Cout,
+                                             blk.mlp.fc1.weight.shape[0], blk.norm2.eps, act, st), "block_tail")
+            return out.view(B, Lq, Cout)
         # 6. y = r + proj(o)                                                 attention.py:281,434
         y = self._linear(L, st, act, o, act, at.proj, torch.float32, B * Lq, residual=r)
         del o, r

@@ -84,6 +84,17 @@ int mvit_mlp_fused_pack(const float* w1, const float* b1, const float* gamma, co
                         void* packed, int C, int hidden, void* stream);
 int mvit_mlp_fused_fwd(const float* x, const void* packed, const float* b2, float* out, int64_t M, int C, int hidden,
                        float eps, int act_dtype, void* stream);
+/* The same kernel with the attention output projection in front (slowfast/models/attention.py:281 proj, :434 x = x_res + x_block,
+ * :436-445 the MLP branch; eval mode):   out = y + fc2(GELU_erf(fc1(LayerNorm(y)))),   y = resid + o . Wproj^T + bproj.
+ *   o: attention output, act-typed [M][C]; resid: fp32 [M][C] (the pooled skip path); out fp32 [M][C] (may alias resid).
+ * y never reaches HBM: the accumulators start at resid, the projection accumulates onto them, LayerNorm is taken from them.
+ *   packed: mvit_block_tail_pack_bytes(C, hidden) bytes written by mvit_block_tail_pack: the proj weight as C/32 chunk images, the
+ *           mvit_mlp_fused_pack image, the proj bias.  wproj fp32 [C][C].  Same shape limits as mvit_mlp_fused_fwd. */
+int64_t mvit_block_tail_pack_bytes(int C, int hidden);
+int mvit_block_tail_pack(const float* wproj, const float* bproj, const float* w1, const float* b1, const float* gamma,
+                         const float* beta, const float* w2, void* packed, int C, int hidden, void* stream);
+int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
+                        int hidden, float eps, int act_dtype, void* stream);
 
 /* Pooling conv + LayerNorm of one of q/k/v for all heads (attention_pool, conv variant:
  * slowfast/models/attention.py:12-83 with the Conv3d of :172-212 and LayerNorm(eps 1e-5) of

@@ -601,3 +601,47 @@ def test_attention_key_split_of_the_ragged_query_tile(half, B, h, Lq, Lk, add_q)
     assert L.mvit_attention_fwd_ws(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), None, B, h, Lq, Lk, scale, add_q, _hip.BF16,
                                    _hip.ptr(ws), nb - 4, _st()) == -1
     assert L.mvit_attention_fwd_workspace_bytes(B, h, 512, Lk, _hip.BF16) == 0 and L.mvit_attention_fwd_workspace_bytes(B, h, Lq, 448, _hip.BF16) == 0
+
+
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,C", [(392, 384), (1, 384), (6272 + 77, 384), (256, 192), (25088 + 3, 192), (256, 96), (100352 + 129, 96), (31, 96)])
+def test_block_tail_proj_mlp_fused_forward(half, M, C):
+    """mvit_block_tail_fwd: y = r + proj(o), out = y + fc2(GELU(fc1(LN(y)))) in one kernel (attention.py:281,434-445) against fp32
+    torch on 16-bit-rounded o; the branch (out - r) is compared so the residual does not hide its error; ragged row counts; both builds;
+    the same rows inside a longer launch are bit-identical; out may alias resid."""
+    L = _hip.lib(half)
+    dt = torch.bfloat16 if half == "bf16" else torch.float16
+    hid = 4 * C
+    sd = 60 + C // 96
+    o = (_rnd(M, C, seed=sd) * 1.2).to(dt)
+    res = _rnd(M, C, seed=sd + 1) * 1.5 + 0.2
+    wp, bpj = _rnd(C, C, seed=sd + 2) * 0.05, 0.1 * _rnd(C, seed=sd + 3)
+    gam, bet = 1 + 0.2 * _rnd(C, seed=sd + 4), 0.1 * _rnd(C, seed=sd + 5)
+    w1, b1 = _rnd(hid, C, seed=sd + 6) * 0.05, 0.1 * _rnd(hid, seed=sd + 7)
+    w2, b2 = _rnd(C, hid, seed=sd + 8) * 0.05, 0.1 * _rnd(C, seed=sd + 9)
+    y = res + F.linear(o.float(), wp, bpj)
+    ref = y + F.linear(F.gelu(F.linear(F.layer_norm(y, (C,), gam, bet, 1e-6), w1, b1)), w2, b2) - res
+    d = {k: t.to(DEV) for k, t in dict(o=o, res=res, wp=wp, bpj=bpj, gam=gam, bet=bet, w1=w1, b1=b1, w2=w2, b2=b2).items()}
+    nb = L.mvit_block_tail_pack_bytes(C, hid)
+    assert nb == (C // 32) * 64 * C + L.mvit_mlp_fused_pack_bytes(C, hid) + (4 * C + 1023) // 1024 * 1024
+    packed = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _hip.check(L.mvit_block_tail_pack(_hip.ptr(d["wp"]), _hip.ptr(d["bpj"]), _hip.ptr(d["w1"]), _hip.ptr(d["b1"]), _hip.ptr(d["gam"]), _hip.ptr(d["bet"]),
+                                      _hip.ptr(d["w2"]), _hip.ptr(packed), C, hid, _st()))
+    out = torch.full((M, C), float("nan"), device=DEV)
+    _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(d["res"]), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(out), M, C, hid, 1e-6,
+                                     _hip.BF16, _st()))
+    got = out.cpu() - res
+    assert torch.isfinite(got).all()
+    _close(got, ref, 2e-2 if half == "bf16" else 3e-3)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print("[block_tail %s M=%d C=%d] max|err| %.3e (scale %.2f) relative L2 %.2e" % (half, M, C, (got - ref).abs().max().item(), ref.abs().max().item(), rel))
+    assert rel <= (6e-3 if half == "bf16" else 8e-4)
+    if M > 300:
+        n = 200
+        sub = torch.empty(n, C, device=DEV)
+        os_, rs_ = d["o"][77:77 + n].contiguous(), d["res"][77:77 + n].contiguous()
+        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(os_), _hip.ptr(rs_), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(sub), n, C, hid, 1e-6, _hip.BF16, _st()))
+        assert torch.equal(sub, out[77:77 + n])
+        inpl = d["res"].clone()
+        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(inpl), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(inpl), M, C, hid, 1e-6, _hip.BF16, _st()))
+        assert torch.equal(inpl, out)

@@ -1,0 +1,5 @@
+#!/bin/bash
+# block tail with / without the attention output projection inside, forward clips/s in one session
+for prec in fp16 bf16; do for f in 1 0 1 0; do
+  echo "tail_fuse=$f $prec streams=3: $(MVIT_TAIL_FUSE=$f python bench.py --mode fwd --precision $prec --streams 3 --steps 30 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
+done; done
