@@ -34,7 +34,7 @@ _SIGS = {
     "mvit_mlp_fused_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_p]),
     "mvit_block_tail_pack_bytes": (c_l, [c_i, c_i]),
     "mvit_block_tail_pack": (c_i, [c_p] * 8 + [c_i, c_i, c_p]),
-    "mvit_block_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_p]),
+    "mvit_block_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),
     "mvit_pool_conv_ln_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "mvit_attention_fwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i, c_i]),

@@ -173,7 +173,8 @@ struct MfCfg {
 template <int CB, int TB, bool PROJ>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restrict__ X, const bf16_t* __restrict__ Oa, const char* __restrict__ Wpk,
                                                            const float* __restrict__ B1p, const float* __restrict__ B2, float* __restrict__ Out,
-                                                           int64_t M, int nch, float eps) {
+                                                           int64_t M, int nch, float eps, const float* __restrict__ Gn, const float* __restrict__ Bn,
+                                                           float eps_n, bf16_t* __restrict__ Un) {
     using K = MfCfg<CB, TB>;
     constexpr int NPC = CB;                               // proj chunks (32 output channels each)
     const char* const Wmlp = Wpk + (PROJ ? NPC * K::WU : 0);
@@ -243,7 +244,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
     char* const st_area = smem + wave * K::ST_PITCH;
     const uint32_t st_lds = lds0 + (uint32_t)wave * K::ST_PITCH;
     {
-        float4 v[TB][K1S][2];
+        // Y^T starts at x (the residual rides on the accumulators; the epilogue adds b2 and stores).  The lane reads channels 16 ks + 8 h + e of
+        // its token, the accumulator layout wants 32 cb + 8 g + 4 h + i: the lane keeps its e = 0..3 (h = 0) / e = 4..7 (h = 1) and swaps the other
+        // four with the lane of the other half (one v_permlane32_swap per register).  Fragment by fragment: nothing large is ever live in
+        // arch VGPRs here -- under register pressure the compiler parks values in ACC registers it believes free, i.e. in the ones this
+        // kernel's asm owns (tests/test_asm_kernel_audit.py).
         const uint64_t seg_mask = (K::PR >= 64) ? ~0ull : ((1ull << K::PR) - 1ull);
         mf_for<0, TB * K::CP>([&](auto P_) {
             constexpr int tb = P_ / K::CP, cp = P_ % K::CP;
@@ -260,11 +265,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the issuing wave's own reads need no barrier behind its vmcnt)
             const char* rp = st_area + r * K::RS + 32 * h;
+            mf_for<0, K::KSP>([&](auto KL_) {
+                constexpr int ks = cp * K::KSP + KL_, cb = ks / 2, gh = ks % 2;
+                const float4 lo = *reinterpret_cast<const float4*>(rp + 64 * KL_), hi = *reinterpret_cast<const float4*>(rp + 64 * KL_ + 16);
+                const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, hi_[4] = {hi.x, hi.y, hi.z, hi.w};
+                uint32_t ge[4], go[4];
 #pragma unroll
-            for (int ksl = 0; ksl < K::KSP; ++ksl) {
-                v[tb][cp * K::KSP + ksl][0] = *reinterpret_cast<const float4*>(rp + 64 * ksl);
-                v[tb][cp * K::KSP + ksl][1] = *reinterpret_cast<const float4*>(rp + 64 * ksl + 16);
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_[i]), __float_as_uint(hi_[i]), false, false);
+                    ge[i] = sw[0];          // g = 2 gh:     channels 16 ks + 4 h + i
+                    go[i] = sw[1];          // g = 2 gh + 1: channels 16 ks + 8 + 4 h + i
+                }
+                mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh)>(make_uint4(ge[0], ge[1], ge[2], ge[3]));
+                mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh + 1)>(make_uint4(go[0], go[1], go[2], go[3]));
+            });
         });
         if constexpr (PROJ) {        // the attention output rows (16 bit): one more pass per token block, straight into the fragment registers
             constexpr int RSO = 2 * C + 16, PRO = C / 8;
@@ -321,68 +335,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
             if (nch > 1) dma_chunk(1);
             if (!is_w2 && nch > 2) dma_chunk(2);
         }
-        // Y^T starts at x: the residual rides on the accumulators (the epilogue adds b2 and stores).  The lane holds
-        // channels 16 ks + 8 h + e of its token, the accumulator layout wants 32 cb + 8 g + 4 h + i: the lane keeps its e = 0..3 (h = 0) /
-        // e = 4..7 (h = 1) and swaps the other four with the lane of the other half (one v_permlane32_swap per register)
-        mf_for<0, K::NXF>([&](auto F) {
-            constexpr int f = F, ks = f / TB, tb = f % TB, cb = ks / 2, gh = ks % 2;
-            const float lo[4] = {v[tb][ks][0].x, v[tb][ks][0].y, v[tb][ks][0].z, v[tb][ks][0].w};
-            const float hi[4] = {v[tb][ks][1].x, v[tb][ks][1].y, v[tb][ks][1].z, v[tb][ks][1].w};
-            float ge[4], go[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[i]), __float_as_uint(hi[i]), false, false);
-                ge[i] = __uint_as_float(sw[0]);          // g = 2 gh:     channels 16 ks + 4 h + i
-                go[i] = __uint_as_float(sw[1]);          // g = 2 gh + 1: channels 16 ks + 8 + 4 h + i
-            }
-            const uint4 ue = make_uint4(__float_as_uint(ge[0]), __float_as_uint(ge[1]), __float_as_uint(ge[2]), __float_as_uint(ge[3]));
-            const uint4 uo = make_uint4(__float_as_uint(go[0]), __float_as_uint(go[1]), __float_as_uint(go[2]), __float_as_uint(go[3]));
-            mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh)>(ue);
-            mf_aput<16 * (cb * TB + tb) + 4 * (2 * gh + 1)>(uo);
-        });
-        if constexpr (!PROJ) {
-    #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) {
-                float s = 0.f;
-    #pragma unroll
-                for (int ks = 0; ks < K1S; ++ks)
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) s += (v[tb][ks][q].x + v[tb][ks][q].y) + (v[tb][ks][q].z + v[tb][ks][q].w);
-                s += __shfl_xor(s, 32, 64);
-                const float mean = s * (1.0f / C);
-                float qq = 0.f;
-    #pragma unroll
-                for (int ks = 0; ks < K1S; ++ks)
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        float4& e = v[tb][ks][q];
-                        e.x -= mean; e.y -= mean; e.z -= mean; e.w -= mean;
-                        qq += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
-                    }
-                qq += __shfl_xor(qq, 32, 64);
-                const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
-    #pragma unroll
-                for (int ks = 0; ks < K1S; ++ks)
-    #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        float4& e = v[tb][ks][q];
-                        e.x *= rstd; e.y *= rstd; e.z *= rstd; e.w *= rstd;
-                    }
-            }
-            mf_for<0, K::NXF>([&](auto F) {
-                constexpr int f = F, ks = f / TB, tb = f % TB;
-                const uint4 u = make_uint4(pack_bf16x2(v[tb][ks][0].x, v[tb][ks][0].y), pack_bf16x2(v[tb][ks][0].z, v[tb][ks][0].w),
-                                           pack_bf16x2(v[tb][ks][1].x, v[tb][ks][1].y), pack_bf16x2(v[tb][ks][1].z, v[tb][ks][1].w));
-                if constexpr (f < K::XACC) mf_aput<K::YREG + 4 * f>(u);
-                else {
-                    xv[f - K::XACC] = *reinterpret_cast<const bf16x8*>(&u);
-                    asm volatile("" : "+v"(xv[f - K::XACC]));
-                }
-            });
-        }
     }
     if constexpr (PROJ) {
-        // ---- y = r + proj(o) + b_proj on the accumulators: chunk p = output channels 32p .. 32p+31 = Y^T tile row p ---------------------
+        // ---- y = r + proj(o) on the accumulators: chunk p = output channels 32p .. 32p+31 = Y^T tile row p (+ b_proj below) -------------
         mf_for<0, NPC>([&](auto P_) {
             constexpr int p = P_;
             asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(K::NPW) : "memory");
@@ -413,52 +368,54 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
             for (int i = 0; i < K::NPW; ++i) dma1(b + 1024 * i, d + 1024 * i);
         }
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");        // the last MFMAs have left the matrix pipe
-        // ---- LayerNorm from the accumulators (+ proj bias, written back: Y^T = y), fragments by the inverse of the start-value swap ----
-        float yv[TB][CB][16];
-        const char* bp = smem + 6 * WU + K::B1BYTES + 16 * h;
-        mf_for<0, TB * CB * 4>([&](auto Q_) {
-            constexpr int tb = Q_ / (CB * 4), cb = (Q_ / 4) % CB, g = Q_ % 4;
-            float4 a;
-            mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-            const float4 bb = *reinterpret_cast<const float4*>(bp + (32 * cb + 8 * g) * 4);
-            a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
-            const uint4 u = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
-            mf_aput<16 * (cb * TB + tb) + 4 * g>(u);
-            yv[tb][cb][4 * g] = a.x; yv[tb][cb][4 * g + 1] = a.y; yv[tb][cb][4 * g + 2] = a.z; yv[tb][cb][4 * g + 3] = a.w;
-        });
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
-            float s = 0.f;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; i += 4) s += (yv[tb][cb][i] + yv[tb][cb][i + 1]) + (yv[tb][cb][i + 2] + yv[tb][cb][i + 3]);
-            s += __shfl_xor(s, 32, 64);
-            const float mean = s * (1.0f / C);
-            float qq = 0.f;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    yv[tb][cb][i] -= mean;
-                    qq = fmaf(yv[tb][cb][i], yv[tb][cb][i], qq);
+    }
+    // ---- LayerNorm FROM the accumulators (Y^T = the rows to normalise), streaming: sum | centred squares | fragments.  The accumulator
+    // registers are read three times (a v_accvgpr_read each) instead of holding the row in arch VGPRs.  PROJ: + proj bias first, written back.
+    {
+        float mean_t[TB], rstd_t[TB];
+        mf_for<0, TB>([&](auto T_) {
+            constexpr int tb = T_;
+            float sm = 0.f;
+            mf_for<0, CB * 4>([&](auto Q_) {
+                constexpr int cb = Q_ / 4, g = Q_ % 4;
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                if constexpr (PROJ) {
+                    const float4 bb = *reinterpret_cast<const float4*>(smem + 6 * WU + K::B1BYTES + (32 * cb + 8 * g + 4 * h) * 4);
+                    a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+                    mf_aput<16 * (cb * TB + tb) + 4 * g>(make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)));
                 }
+                sm += (a.x + a.y) + (a.z + a.w);
+            });
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / C);
+            float qq = 0.f;
+            if constexpr (PROJ) asm volatile("s_nop 1" ::: "memory");       // (v_accvgpr_write -> v_accvgpr_read of the same register)
+            mf_for<0, CB * 4>([&](auto Q_) {
+                constexpr int cb = Q_ / 4, g = Q_ % 4;
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean;
+                qq = fmaf(a.x, a.x, qq); qq = fmaf(a.y, a.y, qq); qq = fmaf(a.z, a.z, qq); qq = fmaf(a.w, a.w, qq);
+            });
             qq += __shfl_xor(qq, 32, 64);
-            const float rstd = 1.0f / sqrtf(qq * (1.0f / C) + eps);
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) yv[tb][cb][i] *= rstd;
-        }
+            mean_t[tb] = mean;
+            rstd_t[tb] = 1.0f / sqrtf(qq * (1.0f / C) + eps);
+        });
         // lane (r, h) holds channels 32 cb + 8 g + 4 h + i; fragment k-step 2 cb + gh wants 32 cb + 16 gh + 8 h + e: the lane keeps
         // g = 2 gh + h and receives the other half's registers of the same g (v_permlane32_swap of the g-even with the g-odd register)
         mf_for<0, K::NXF>([&](auto F) {
             constexpr int f = F, ks = f / TB, tb = f % TB, cb = ks / 2, gh = ks % 2;
+            float4 e, o;
+            mf_aget4<16 * (cb * TB + tb) + 4 * (2 * gh)>(e);
+            mf_aget4<16 * (cb * TB + tb) + 4 * (2 * gh + 1)>(o);
+            const float m_ = mean_t[tb], rs_ = rstd_t[tb];
+            const float ev[4] = {(e.x - m_) * rs_, (e.y - m_) * rs_, (e.z - m_) * rs_, (e.w - m_) * rs_};
+            const float ov[4] = {(o.x - m_) * rs_, (o.y - m_) * rs_, (o.z - m_) * rs_, (o.w - m_) * rs_};
             float lo[4], hi[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(yv[tb][cb][4 * (2 * gh) + i]), __float_as_uint(yv[tb][cb][4 * (2 * gh + 1) + i]),
-                                                                 false, false);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ev[i]), __float_as_uint(ov[i]), false, false);
                 lo[i] = __uint_as_float(sw[0]);
                 hi[i] = __uint_as_float(sw[1]);
             }
@@ -701,6 +658,97 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped LDS-DMA pieces of the last iterations)
     __builtin_amdgcn_s_barrier();                          // every wave is done with the rings
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    if (Un != nullptr) {
+        // ---- ... and the NEXT block's norm1 on the rows just finished: u = LayerNorm(out; Gn, Bn) as the 16-bit operand of its qkv GEMM
+        // (attention.py:421): the wave holds whole rows here, the standalone LayerNorm launch (one more read of out) disappears.
+        float* const ex = reinterpret_cast<float*>(smem + 4 * K::ST_PITCH);          // b2 | gamma | beta, fp32 [C] each
+        for (int i = tid; i < 3 * C / 4; i += 256) {
+            const int a = i / (C / 4), j = i - a * (C / 4);
+            const float* src = a == 0 ? B2 : (a == 1 ? Gn : Bn);
+            reinterpret_cast<float4*>(ex)[i] = *reinterpret_cast<const float4*>(src + 4 * j);
+        }
+        __syncthreads();
+        float mean_t[TB], rstd_t[TB];
+        mf_for<0, TB>([&](auto T_) {                 // statistics of out = Y^T + b2, streaming over the accumulators (nothing large in arch VGPRs)
+            constexpr int tb = T_;
+            float sm = 0.f;
+            mf_for<0, CB * 4>([&](auto Q_) {
+                constexpr int cb = Q_ / 4, g = Q_ % 4;
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
+                sm += ((a.x + bb.x) + (a.y + bb.y)) + ((a.z + bb.z) + (a.w + bb.w));
+            });
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / C);
+            float qq = 0.f;
+            mf_for<0, CB * 4>([&](auto Q_) {
+                constexpr int cb = Q_ / 4, g = Q_ % 4;
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
+                const float d0 = a.x + bb.x - mean, d1 = a.y + bb.y - mean, d2 = a.z + bb.z - mean, d3 = a.w + bb.w - mean;
+                qq = fmaf(d0, d0, qq); qq = fmaf(d1, d1, qq); qq = fmaf(d2, d2, qq); qq = fmaf(d3, d3, qq);
+            });
+            qq += __shfl_xor(qq, 32, 64);
+            mean_t[tb] = mean;
+            rstd_t[tb] = 1.0f / sqrtf(qq * (1.0f / C) + eps_n);
+        });
+        constexpr int PRU = K::PR / 2, NIU = K::NI / 2, RPIU = 192 / PRU, RSU = K::SEG / 2 + 16;      // the 16-bit image: half the bytes per row segment
+        static_assert(192 % PRU == 0 && NIU % 3 == 0, "column pattern of the 16-bit side");
+        int row_c[3], col_c[3], row_u[3], col_u[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int q = 64 * c + lane;
+            row_c[c] = q / K::PR;
+            col_c[c] = q - row_c[c] * K::PR;
+            row_u[c] = q / PRU;
+            col_u[c] = q - row_u[c] * PRU;
+        }
+        mf_for<0, TB * K::CP>([&](auto P_) {
+            constexpr int tb = P_ / K::CP, cp = P_ % K::CP, NCB = CB / K::CP;
+            char* wp = st_area + r * K::RS + 16 * h;
+            mf_for<0, NCB * 4>([&](auto Q_) {
+                constexpr int cbl = Q_ / 4, g = Q_ % 4, cb = cp * NCB + cbl;
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
+                *reinterpret_cast<float4*>(wp + (32 * cbl + 8 * g) * 4) = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mf_for<0, K::NI>([&](auto I_) {
+                constexpr int i = I_, c = i % 3;
+                const int row = row_c[c] + (i / 3) * K::RPI;
+                const float4 a = *reinterpret_cast<const float4*>(st_area + row * K::RS + 16 * col_c[c]);
+                const int64_t t = tok0 + 32 * tb + row;
+                if (t < M) *reinterpret_cast<float4*>(Out + t * C + cp * (C / K::CP) + 4 * col_c[c]) = a;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            char* wu = st_area + r * RSU + 8 * h;
+            mf_for<0, NCB * 4>([&](auto Q_) {
+                constexpr int cbl = Q_ / 4, g = Q_ % 4, cb = cp * NCB + cbl;
+                const float4 gg = *reinterpret_cast<const float4*>(ex + C + 32 * cb + 8 * g + 4 * h);
+                const float4 be = *reinterpret_cast<const float4*>(ex + 2 * C + 32 * cb + 8 * g + 4 * h);
+                const float m_ = mean_t[tb], rs_ = rstd_t[tb];
+                float4 a;
+                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
+                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
+                const float u0 = fmaf((a.x + bb.x - m_) * rs_, gg.x, be.x), u1 = fmaf((a.y + bb.y - m_) * rs_, gg.y, be.y);
+                const float u2 = fmaf((a.z + bb.z - m_) * rs_, gg.z, be.z), u3 = fmaf((a.w + bb.w - m_) * rs_, gg.w, be.w);
+                *reinterpret_cast<uint2*>(wu + (32 * cbl + 8 * g) * 2) = make_uint2(pack_bf16x2(u0, u1), pack_bf16x2(u2, u3));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mf_for<0, NIU>([&](auto I_) {
+                constexpr int i = I_, c = i % 3;
+                const int row = row_u[c] + (i / 3) * RPIU;
+                const uint4 a = *reinterpret_cast<const uint4*>(st_area + row * RSU + 16 * col_u[c]);
+                const int64_t t = tok0 + 32 * tb + row;
+                if (t < M) *reinterpret_cast<uint4*>(Un + t * C + cp * (C / K::CP) + 8 * col_u[c]) = a;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        return;
+    }
     {
         int row_c[3], col_c[3];
 #pragma unroll
@@ -854,9 +902,10 @@ extern "C" int mvit_block_tail_pack(const float* wproj, const float* bproj, cons
 }
 
 template <int CB, int TB, bool PROJ>
-static int mf_launch(const float* x, const void* o, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st) {
+static int mf_launch(const float* x, const void* o, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st,
+                     const float* gn = nullptr, const float* bn = nullptr, float eps_n = 0.f, void* un = nullptr) {
     using K = MfCfg<CB, TB>;
-    const int ring = 6 * K::WU + K::B1BYTES + (PROJ ? K::BPBYTES : 0), stage = 4 * K::ST_PITCH;       // rings + biases | the prologue's / epilogue's staging areas
+    const int ring = 6 * K::WU + K::B1BYTES + (PROJ ? K::BPBYTES : 0), stage = 4 * K::ST_PITCH + 12 * K::C;       // rings + biases | staging areas (+ b2, gamma, beta of the emitted LayerNorm)
     const int smem = ring > stage ? ring : stage;
     static DevFlags attr_tab;
     bool& attr_done = dev_flag(attr_tab);
@@ -870,7 +919,8 @@ static int mf_launch(const float* x, const void* o, const void* packed, const fl
     const int nch = hidden / 32;
     const char* wpk = reinterpret_cast<const char*>(packed);
     const float* b1p = reinterpret_cast<const float*>(wpk + (PROJ ? (int64_t)CB * K::WU : 0) + (int64_t)nch * K::CHB);
-    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB, PROJ>), dim3((unsigned)tiles), dim3(256), smem, st, x, (const bf16_t*)o, wpk, b1p, b2, out, M, nch, eps);
+    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB, PROJ>), dim3((unsigned)tiles), dim3(256), smem, st, x, (const bf16_t*)o, wpk, b1p, b2, out, M, nch, eps, gn, bn,
+                       eps_n, (bf16_t*)un);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -889,15 +939,17 @@ extern "C" int mvit_mlp_fused_fwd(const float* x, const void* packed, const floa
     }
 }
 extern "C" int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
-                                   int hidden, float eps, int act_dtype, void* stream) {
+                                   int hidden, float eps, const float* next_gamma, const float* next_beta, float next_eps, void* next_u,
+                                   int act_dtype, void* stream) {
     if (!o || !resid || !packed || !b2 || !out || M < 0) return MVIT_EINVAL;
+    if (next_u && (!next_gamma || !next_beta)) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EUNSUPPORTED;
     if (!mf_shape_ok(C, hidden)) return MVIT_EUNSUPPORTED;
     if (M == 0) return MVIT_OK;
     hipStream_t st = as_stream(stream);
     switch (C) {
-        case 384: return mf_launch<12, 1, true>(resid, o, packed, b2, out, M, hidden, eps, st);
-        case 192: return mf_launch<6, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
-        default: return mf_launch<3, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
+        case 384: return mf_launch<12, 1, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
+        case 192: return mf_launch<6, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
+        default: return mf_launch<3, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
     }
 }

@@ -89,12 +89,16 @@ int mvit_mlp_fused_fwd(const float* x, const void* packed, const float* b2, floa
  *   o: attention output, act-typed [M][C]; resid: fp32 [M][C] (the pooled skip path); out fp32 [M][C] (may alias resid).
  * y never reaches HBM: the accumulators start at resid, the projection accumulates onto them, LayerNorm is taken from them.
  *   packed: mvit_block_tail_pack_bytes(C, hidden) bytes written by mvit_block_tail_pack: the proj weight as C/32 chunk images, the
- *           mvit_mlp_fused_pack image, the proj bias.  wproj fp32 [C][C].  Same shape limits as mvit_mlp_fused_fwd. */
+ *           mvit_mlp_fused_pack image, the proj bias.  wproj fp32 [C][C].  Same shape limits as mvit_mlp_fused_fwd.
+ *   next_u (NULL = off): act-typed [M][C] receiving LayerNorm(out; next_gamma, next_beta, next_eps) -- the following block's norm1
+ *           (attention.py:421), the operand of its qkv GEMM: the kernel holds whole rows at its end, so the standalone LayerNorm launch
+ *           of the next block (one more read of out) is not needed. */
 int64_t mvit_block_tail_pack_bytes(int C, int hidden);
 int mvit_block_tail_pack(const float* wproj, const float* bproj, const float* w1, const float* b1, const float* gamma,
                          const float* beta, const float* w2, void* packed, int C, int hidden, void* stream);
 int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
-                        int hidden, float eps, int act_dtype, void* stream);
+                        int hidden, float eps, const float* next_gamma, const float* next_beta, float next_eps, void* next_u,
+                        int act_dtype, void* stream);
 
 /* Pooling conv + LayerNorm of one of q/k/v for all heads (attention_pool, conv variant:
  * slowfast/models/attention.py:12-83 with the Conv3d of :172-212 and LayerNorm(eps 1e-5) of

@@ -628,8 +628,16 @@ def test_block_tail_proj_mlp_fused_forward(half, M, C):
     _hip.check(L.mvit_block_tail_pack(_hip.ptr(d["wp"]), _hip.ptr(d["bpj"]), _hip.ptr(d["w1"]), _hip.ptr(d["b1"]), _hip.ptr(d["gam"]), _hip.ptr(d["bet"]),
                                       _hip.ptr(d["w2"]), _hip.ptr(packed), C, hid, _st()))
     out = torch.full((M, C), float("nan"), device=DEV)
+    g1n, b1n = (1 + 0.2 * _rnd(C, seed=sd + 10)).to(DEV), (0.1 * _rnd(C, seed=sd + 11)).to(DEV)
+    un = torch.full((M, C), float("nan"), dtype=dt, device=DEV)
     _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(d["res"]), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(out), M, C, hid, 1e-6,
-                                     _hip.BF16, _st()))
+                                     _hip.ptr(g1n), _hip.ptr(b1n), 1e-6, _hip.ptr(un), _hip.BF16, _st()))
+    # the emitted norm1 of the next block = LayerNorm of the rows this very kernel wrote; and without it the output is bit-identical
+    _close(un, F.layer_norm(out.cpu(), (C,), g1n.cpu(), b1n.cpu(), 1e-6), 8e-3 if half == "bf16" else 1.5e-3)
+    out_plain = torch.empty_like(out)
+    _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(d["res"]), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(out_plain), M, C, hid, 1e-6,
+                                     None, None, 0.0, None, _hip.BF16, _st()))
+    assert torch.equal(out_plain, out)
     got = out.cpu() - res
     assert torch.isfinite(got).all()
     _close(got, ref, 2e-2 if half == "bf16" else 3e-3)
@@ -640,8 +648,10 @@ def test_block_tail_proj_mlp_fused_forward(half, M, C):
         n = 200
         sub = torch.empty(n, C, device=DEV)
         os_, rs_ = d["o"][77:77 + n].contiguous(), d["res"][77:77 + n].contiguous()
-        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(os_), _hip.ptr(rs_), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(sub), n, C, hid, 1e-6, _hip.BF16, _st()))
+        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(os_), _hip.ptr(rs_), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(sub), n, C, hid, 1e-6, None, None, 0.0, None,
+                                         _hip.BF16, _st()))
         assert torch.equal(sub, out[77:77 + n])
         inpl = d["res"].clone()
-        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(inpl), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(inpl), M, C, hid, 1e-6, _hip.BF16, _st()))
+        _hip.check(L.mvit_block_tail_fwd(_hip.ptr(d["o"]), _hip.ptr(inpl), _hip.ptr(packed), _hip.ptr(d["b2"]), _hip.ptr(inpl), M, C, hid, 1e-6, None, None, 0.0,
+                                         None, _hip.BF16, _st()))
         assert torch.equal(inpl, out)
