@@ -145,8 +145,10 @@ _ATT_TAIL = os.environ.get("MVIT_ATT_TAIL_SPLIT", "0") == "1"
 
 
 def attention_fwd(L, q, k, v, o, lse, B, h, Lq, Lk, scale, add_q, act, st):
-    """mvit_attention_fwd_ws with its workspace (key-split ragged query tile, include/mvit_hip.h); the workspace is an ordinary
-    stream-ordered torch allocation."""
+    """mvit_attention_fwd, or (MVIT_ATT_TAIL_SPLIT=1) mvit_attention_fwd_ws with its workspace (key-split ragged query tile,
+    include/mvit_hip.h); the workspace is an ordinary stream-ordered torch allocation.  A batch-dependent choice (split only where a launch
+    fills whole rounds) was tried for the training forward: the train step moved by 0.1 ms (162.8 -> 163.1 clips/s, noise) and the
+    per-clip logits stopped being batch-independent (tests/test_hip_train.py::test_bench_size_bf16_train_step_properties): not kept."""
     nb = L.mvit_attention_fwd_workspace_bytes(B, h, Lq, Lk, act) if _ATT_TAIL else 0
     if nb <= 0:
         return L.mvit_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, st)
