@@ -42,8 +42,9 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_CLIP = {448: 856.45, 224: 127.73}   # SURVEY.md section 8d (2 FLOP/MAC, GEMM + conv terms)
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FWD = "r3_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh)
-TRAFFIC_BWD = "r3_attn_bwd_hbm_traffic.json"
+TRAFFIC_FWD = "r4_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh via tools/r4_profiles.sh)
+TRAFFIC_BWD = "r4_attn_bwd_hbm_traffic.json"
+TRAFFIC_TAIL = "r4_block_tail_hbm_traffic.json"  # ... per launch of the fused block tail at the stage-3 shape
 
 
 def attention_flops(geoms, B):
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--crop", type=int, default=448, choices=[224, 448])
     ap.add_argument("--precision", default=None, choices=["bf16", "fp16", "fp32"],
                     help="default: HIP.PRECISION auto = bf16 for the train modes, fp16 (the arithmetic that meets the 1e-3 logit gate) for fwd / window")
-    ap.add_argument("--streams", type=int, default=3, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
+    ap.add_argument("--streams", type=int, default=2, help="inference: sub-batches on separate HIP streams (cfg HIP.STREAMS)")
     ap.add_argument("--train-streams", type=int, default=1, help="training: sub-batches on separate HIP streams (cfg HIP.TRAIN_STREAMS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -293,7 +294,7 @@ def main():
             FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied); None for any other configuration.  The file
             records the commit of the kernels it was measured on (`measured_at_commit`), echoed here so staleness is visible."""
             path = os.path.join(ROOT, "profiles", fname)
-            if not (args.batch == 8 and args.crop == 448 and args.precision == "bf16" and os.path.exists(path)):
+            if not (args.batch == 8 and args.crop == 448 and args.precision in ("bf16", "fp16") and os.path.exists(path)):      # (both 16-bit builds move the same bytes)
                 return None
             try:
                 doc = json.load(open(path))
@@ -317,6 +318,27 @@ def main():
             extra_rooflines["roofline_attention_fwd"] = fwd_rl
         else:
             roofline = fwd_rl
+            if act:
+                # second family of the forward: the fused block tail (proj + norm2 + fc1 + GELU + fc2 + residual in one kernel, csrc/mlp_fused.hip),
+                # timed alone at the steady stage-3 shape (11 of 16 blocks); algorithmic FLOPs = 2 M C^2 (proj) + 16 M C^2 (fc1 + fc2)
+                g3 = core.geoms[len(core.geoms) // 2]
+                Mt, Ct = clips_pl * g3.lq, g3.dim_out
+                blk = core.blocks[len(core.geoms) // 2]
+                tk = core._tail_packed(blk, act)
+                if tk is not None:
+                    o_ = torch.randn(Mt, Ct, device=dev).to(adt)
+                    r_ = torch.randn(Mt, Ct, device=dev)
+                    out_ = torch.empty_like(r_)
+                    ms = timed(lambda: _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o_), _hip.ptr(r_), _hip.ptr(tk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out_), Mt, Ct,
+                                                                         4 * Ct, blk.norm2.eps, None, None, 0.0, None, act, st)))
+                    fl_t = 18.0 * Mt * Ct * Ct
+                    ach = fl_t / (ms * 1e-3) / 1e12
+                    extra_rooflines["roofline_block_tail"] = {
+                        "kernel": "mlp_fused_kernel<12, 1, true> (mvit_block_tail_fwd, %s), M = %d x C = %d" % (sfx, Mt, Ct), "bound": "mfma", "achieved": round(ach, 2),
+                        "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(TRAFFIC_TAIL, "traffic_bytes_per_launch", "block_tail"),
+                        "launches": 11 * sub, "clips_per_launch": clips_pl, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl_t / 1e9, 2),
+                        "algorithmic_hbm_bytes_per_launch": Mt * Ct * 10}
+                    del o_, r_, out_
         roofline["traffic_source"] = traffic_src
 
     # ---- train mode: the eval-forward record of BASELINE configs[1] beside the headline (north star: >= 30 % on THIS number) ----
