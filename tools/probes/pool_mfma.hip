@@ -102,6 +102,10 @@ __global__ __launch_bounds__(PM_NT, 1) void pool_mfma_probe_kernel(const uint16_
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem);
     for (int t = 0; t < PM_T; ++t) {
         uint4 nbuf[3];
+#ifdef PM_ABL_NOSTAGE
+        nbuf[0] = nbuf[1] = nbuf[2] = make_uint4(0, 0, 0, 0);
+        if (t > 100)
+#endif
         stage_load(t + 2, nbuf);                               // plane t+2 -> slot of plane t-2 (free): requested before the matrix work
         uint32_t toff[14];
 #pragma unroll
@@ -122,10 +126,17 @@ __global__ __launch_bounds__(PM_NT, 1) void pool_mfma_probe_kernel(const uint16_
             if (j == 0) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (i + 7 <= 56) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bfr[i % 7]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[i % 7]));
+#ifdef PM_ABL_NOMFMA
+            acc[u][0] += __builtin_bit_cast(float, (int)bfr[i % 7][0]);
+#else
             acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma16_t, af[j]), __builtin_bit_cast(mfma16_t, bfr[i % 7]), acc[u], 0, 0, 0);
+#endif
             if (i + 7 < 56) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[i % 7]) : "v"(base[(i + 7) / 14] + toff[(i + 7) % 14]));
         }
         // D^T: lane (n = position, mq = kq) holds channels 16 g + 4 mq .. + 3 of position n
+#ifdef PM_ABL_NOSTORE
+        if (acc[0][0] == 12345.f)
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int rb = u >> 1, x0 = (u & 1) * 12;
