@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
                                                        int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
-        for (int p = 1; p < nparts; ++p) {
+#pragma unroll 8
+        for (int p = 1; p < nparts; ++p) {                 // (fixed order; unrolled so that 8 loads are in flight)
             const float4 t = *reinterpret_cast<const float4*>(part + p * stride + 4 * i);
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
@@ -125,7 +126,21 @@ __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __res
     char* sD = smem + SW_PBYTES;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int ci = blockIdx.x % 3;
+    // Workgroup -> (row group, input channel): the three channels of a group sit on ONE XCD (ids xcd + 8 (3k + ci): blockIdx.x % 8 picks
+    // the XCD), so the token gradients they all read come from HBM once and from that XCD's L2 twice; a group walks a CONTIGUOUS run of
+    // output rows, so the 3 of 7 input rows that consecutive output rows share are L2 hits as well.
+    int grp, ci;
+    {
+        const int nwg0 = gridDim.x / 3;
+        if ((nwg0 & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            grp = (slot / 3) * 8 + xcd;
+            ci = slot % 3;
+        } else {
+            grp = blockIdx.x / 3;
+            ci = blockIdx.x % 3;
+        }
+    }
     const int nks = (So + 15) / 16;
     for (int i = tid; i < (SW_PBYTES + SW_DBYTES) / 16; i += 192) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
@@ -152,7 +167,9 @@ __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __res
     const int nrows = B * To * So;        // output rows (b, to, yo)
     const int nwg = gridDim.x / 3;
     const int x4 = S / 4;                 // float4 groups per input row == So
-    for (int row = blockIdx.x / 3; row < nrows; row += nwg) {
+    const int per = nrows / nwg, rem = nrows - per * nwg;
+    const int row0 = grp * per + (grp < rem ? grp : rem), row1 = row0 + per + (grp < rem ? 1 : 0);
+    for (int row = row0; row < row1; ++row) {
         const int yo = row % So;
         const int to = (row / So) % To;
         const int b = row / (So * To);
@@ -225,7 +242,217 @@ __global__ __launch_bounds__(192) void stem_wgrad_mfma_kernel(const float* __res
                 for (int i = 0; i < 16; ++i) {
                     const int c = 32 * cb + (i & 3) + 8 * (i >> 2) + 4 * h;
                     // part: slab of this row group (the three input-channel workgroups of a group write disjoint columns)
-                    part[(int64_t)(blockIdx.x / 3) * (96 * 441) + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx] = acc[cb][kb][i];
+                    part[(int64_t)grp * (96 * 441) + (int64_t)c * 441 + ci * 147 + wave * 49 + dy * 7 + dx] = acc[cb][kb][i];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2 (round 4) of the matrix-core weight gradient: the same GEMM (contraction over the tokens of an output row), re-staged.
+//   The r2 kernel above spends its time staging, not on memory (profiles/r4_stem_ring.txt: moving its workgroups so that the token
+//   gradients come from HBM once changed nothing): every pixel is written to one or two of 8 "dx planes" with 2-byte LDS stores, the
+//   token gradients are converted three times (once per input-channel workgroup), and all of it waits for its loads with the MFMAs idle.
+//   Here one workgroup (6 waves) owns ALL 18 column blocks of dW -- wave w: blocks 3w .. 3w+2 of (plane = ci*3+dt, dy half), 9 accumulator
+//   tiles -- and walks a contiguous run of output rows (b, to, yo):
+//   * the B operand comes from LINEAR 16-bit pixel rows [plane][row slot][4 zero pixels | S pixels]: a token's 8 columns are pixels
+//     4x-4 .. 4x+3 (column 0 has no weight: dx = column - 1), i.e. 16 contiguous bytes at byte 8x, and ds_read_tr16_b64 -- the read that
+//     already transposes the token gradients into A fragments -- takes one address per lane, so tokens 8 bytes apart are as good as
+//     a dense matrix.  Each pixel is converted and written once (8-byte stores);
+//   * consecutive output rows share 3 of their 7 input rows: a ring of 8 row slots per plane (slot = yi & 7), 4 new rows per step;
+//   * the token gradients of the NEXT row travel by LDS-DMA (a 43 KB linear copy) into an fp32 staging area and the next 4 x 9 pixel rows
+//     into registers while the MFMAs of the current row run; two barriers per row.
+// ------------------------------------------------------------------------------------------------
+#define SG_NT 384
+#define SG_PXB 912                         // bytes of a pixel row: 4 + 448 + 4 pixels of 16 bit
+#define SG_RING (9 * 8 * SG_PXB)           // 65,664
+#define SG_DROWB 192
+#define SG_SD (112 * SG_DROWB)             // 21,504: token gradients of the row, 16 bit [token][96]
+#define SG_STG (112 * 384)                 // 43,008: the next row's token gradients, fp32, as they lie in memory
+#define SG_LDS (SG_RING + SG_SD + SG_STG)  // 130,176
+
+__global__ __launch_bounds__(SG_NT, 1) void stem_wgrad_rows_kernel(const float* __restrict__ clip, const float* __restrict__ dxg, int B, int T, int S,
+                                                                   int To, int So, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    char* const sD = smem + SG_RING;
+    char* const stg = smem + SG_RING + SG_SD;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int nks = So / 16 + ((So & 15) ? 1 : 0);
+    const int x4 = S / 4;                                          // quads per pixel row == So
+    for (int i = tid; i < SG_LDS / 16; i += SG_NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    const int nrows = B * To * So;                                 // output rows (b, to, yo)
+    const int G = gridDim.x;
+    const int per = nrows / G, rem = nrows - per * G;
+    const int grp = blockIdx.x;
+    const int row0 = grp * per + (grp < rem ? grp : rem), row1 = row0 + per + (grp < rem ? 1 : 0);
+
+    f32x16 acc[3][3];                                              // [c block][column block of this wave]
+#pragma unroll
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][j][e] = 0.f;
+
+    // fragment addressing (ds_read_tr16_b64: the lane names 4 consecutive columns of one row; a 16-lane group = 4 rows x 16 columns)
+    const int i16 = lane & 15, gi = lane >> 4;
+    const int a_lane = (8 * h + (i16 >> 2)) * SG_DROWB + (16 * (gi & 1) + 4 * (i16 & 3)) * 2;       // + ks * 16 rows, + cb * 64 B; hi: + 4 rows
+    const int cidx = 4 * (gi & 1) + (i16 & 3);                     // 4-column chunk of the 32 columns: dy = 4 kb + (cidx >> 1), pixels 4 (cidx & 1) ..
+    const int b_lane = (8 * h + (i16 >> 2)) * 8 + (cidx & 1) * 8;  // + ks * 128; hi: + 32
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem);
+
+    auto row_pos = [&](int row, int& b, int& to, int& yo) {
+        yo = row % So;
+        to = (row / So) % To;
+        b = row / (So * To);
+    };
+    // token gradients of `row` -> fp32 staging: a linear copy of So * 384 bytes, 1 KiB per wave instruction
+    auto dma_tokens = [&](int row) {
+        const char* src = reinterpret_cast<const char*>(dxg + (int64_t)row * So * 96);
+        const int nchunk = So * 384 / 1024;
+        const uint32_t l16 = 16u * lane;
+        for (int c = wave; c < nchunk; c += 6) {
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + SG_RING + SG_SD + (uint32_t)c * 1024u);
+            const char* sc = src + (int64_t)c * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(l16), "s"(sc) : "memory");
+        }
+    };
+    // the 4 new pixel rows (yi = 4 yo .. 4 yo + 3) of the 9 planes: wave w takes plane-rows w, w + 6, .. (plane = pr / 4, row = pr % 4),
+    // a lane the quads lane and lane + 64 of a row
+    auto px_load = [&](float4 (&pv)[6][2], int b, int to, int yo) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int pr = wave + 6 * k, pl = pr >> 2, nr = pr & 3;
+            const int ci = pl / 3, dt = pl - 3 * ci;
+            const int ti = 2 * to + dt - 1, yi = 4 * yo + nr;
+            const bool ok = ti >= 0 && ti < T && yi < S;
+            const float* src = clip + ((((int64_t)b * 3 + ci) * T + (ok ? ti : 0)) * S + (ok ? yi : 0)) * S;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int xq = lane + 64 * q;
+                pv[k][q] = load4(src + 4 * (xq < x4 ? xq : 0));
+            }
+        }
+    };
+    auto px_write = [&](const float4 (&pv)[6][2], int to, int yo) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int pr = wave + 6 * k, pl = pr >> 2, nr = pr & 3;
+            const int dt = pl % 3;
+            const int ti = 2 * to + dt - 1, yi = 4 * yo + nr;
+            const bool ok = ti >= 0 && ti < T && yi < S;
+            char* dst = ring + (pl * 8 + (yi & 7)) * SG_PXB + 8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int xq = lane + 64 * q;
+                uint2 o = make_uint2(pack_bf16x2(pv[k][q].x, pv[k][q].y), pack_bf16x2(pv[k][q].z, pv[k][q].w));
+                if (!ok) o = make_uint2(0u, 0u);
+                if (xq < x4) *reinterpret_cast<uint2*>(dst + 8 * xq) = o;
+            }
+        }
+    };
+    // rows yi = 4 yo - 3 .. 4 yo - 1 (dy = 0 .. 2) of the 9 planes, synchronously: at the head of a run; a row with yo = 0 has them
+    // outside the image (zero rows)
+    auto px_head = [&](int b, int to, int yo) {
+        for (int pr = wave; pr < 27; pr += 6) {
+            const int pl = pr / 3, nr = pr - 3 * pl;
+            const int ci = pl / 3, dt = pl - 3 * ci;
+            const int ti = 2 * to + dt - 1, yi = 4 * yo - 3 + nr;
+            const bool ok = ti >= 0 && ti < T && yi >= 0 && yi < S;
+            const float* src = clip + ((((int64_t)b * 3 + ci) * T + (ok ? ti : 0)) * S + (ok ? yi : 0)) * S;
+            char* dst = ring + (pl * 8 + ((yi + 8) & 7)) * SG_PXB + 8;
+            for (int xq = lane; xq < x4; xq += 64) {
+                const float4 v = load4(src + 4 * xq);
+                uint2 o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                if (!ok) o = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(dst + 8 * xq) = o;
+            }
+        }
+    };
+
+    if (row0 < row1) {
+        int b, to, yo;
+        row_pos(row0, b, to, yo);
+        float4 pv[6][2];
+        __syncthreads();                                           // LDS is zero
+        dma_tokens(row0);
+        px_load(pv, b, to, yo);
+        if (yo > 0) px_head(b, to, yo);
+        for (int row = row0; row < row1; ++row) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the copy has landed
+            __syncthreads();                                       // #1: all of it has; the previous row's MFMAs are done with sD and the ring
+            // ---- staging -> 16-bit [token][96]; the new pixel rows -> ring ---------------------------------------------------------------
+            for (int i = tid; i < So * 12; i += SG_NT) {
+                const int tok = i / 12, c8 = i - tok * 12;
+                const float4 lo = *reinterpret_cast<const float4*>(stg + tok * 384 + c8 * 32);
+                const float4 hi = *reinterpret_cast<const float4*>(stg + tok * 384 + c8 * 32 + 16);
+                uint4 o;
+                o.x = pack_bf16x2(lo.x, lo.y); o.y = pack_bf16x2(lo.z, lo.w); o.z = pack_bf16x2(hi.x, hi.y); o.w = pack_bf16x2(hi.z, hi.w);
+                *reinterpret_cast<uint4*>(sD + tok * SG_DROWB + c8 * 16) = o;
+            }
+            if (yo == 0 && row != row0) {                          // a new frame: rows -3 .. -1 (slots 5, 6, 7) lie above the image
+                for (int i = tid; i < 27 * (SG_PXB / 16); i += SG_NT) {
+                    const int pr = i / (SG_PXB / 16), pc = i - pr * (SG_PXB / 16);
+                    *reinterpret_cast<uint4*>(ring + ((pr / 3) * 8 + 5 + pr % 3) * SG_PXB + 16 * pc) = make_uint4(0, 0, 0, 0);
+                }
+            }
+            px_write(pv, to, yo);
+            __syncthreads();                                       // #2: operands complete, staging area free
+            const int cyo = yo;                                    // (to / yo move on to the next row below)
+            if (row + 1 < row1) {                                  // the next row's data: under the MFMAs below
+                dma_tokens(row + 1);
+                row_pos(row + 1, b, to, yo);
+                px_load(pv, b, to, yo);
+            }
+            // ---- dW += dxg^T . patches over the row's tokens -------------------------------------------------------------------------------
+            int baddr[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int nb = 3 * wave + j, pl = nb >> 1, kb = nb & 1;
+                int dy = 4 * kb + (cidx >> 1);
+                dy = dy < 7 ? dy : 6;                              // (column block 1, dy = 7: padding columns, dropped at the end)
+                baddr[j] = (pl * 8 + ((4 * cyo - 3 + dy + 8) & 7)) * SG_PXB + b_lane;
+            }
+            for (int ks = 0; ks < nks; ++ks) {
+                bf16x8 af[3], bf[3];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    const char* ap = sD + a_lane + ks * 16 * SG_DROWB + cb * 64;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(ap));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(ap + 4 * SG_DROWB));
+                    af[cb][0] = lo[0]; af[cb][1] = lo[1]; af[cb][2] = lo[2]; af[cb][3] = lo[3];
+                    af[cb][4] = hi[0]; af[cb][5] = hi[1]; af[cb][6] = hi[2]; af[cb][7] = hi[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const char* bp = ring + baddr[j] + ks * 128;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(bp));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sw_lds_b4*)(bp + 32));
+                    bf[j][0] = lo[0]; bf[j][1] = lo[1]; bf[j][2] = lo[2]; bf[j][3] = lo[3];
+                    bf[j][4] = hi[0]; bf[j][5] = hi[1]; bf[j][6] = hi[2]; bf[j][7] = hi[3];
+                }
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[cb][j] = mfma16(af[cb], bf[j], acc[cb][j]);
+            }
+        }
+    }
+    // D[c][column]: row c = 32 cb + (e & 3) + 8 (e >> 2) + 4 h; column = lane & 31 -> (dy = 4 kb + (col >> 3), dx = (col & 7) - 1)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int nb = 3 * wave + j, pl = nb >> 1, kb = nb & 1;
+        const int dy = 4 * kb + (r >> 3), dx = (r & 7) - 1;
+        if (dy < 7 && dx >= 0) {
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = 32 * cb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    part[(int64_t)grp * (96 * 441) + (int64_t)c * 441 + pl * 49 + dy * 7 + dx] = acc[cb][j][e];
                 }
         }
     }
@@ -273,19 +500,28 @@ __global__ __launch_bounds__(256) void stem_pos_bwd_kernel(const float* __restri
 // 16-bit copies of the clip rows and token gradients (fp32 accumulation).  Positional-embedding gradients are fp32 sums.
 // workspace (mvit_stem_bwd_workspace_bytes): per-workgroup partial slabs added in a fixed order -> bit-reproducible gradients;
 // NULL: the workgroups meet in fp32 atomics.
-static int stem_wgrad_groups(int B, int T, int S, int act_dtype, bool* mfma) {
+static bool stem_wgrad_v2() {                        // A/B switch: MVIT_STEM_WGRAD_V1=1 runs the r2 kernel
+    static const bool v1 = getenv("MVIT_STEM_WGRAD_V1") && getenv("MVIT_STEM_WGRAD_V1")[0] == '1';
+    return !v1;
+}
+// *mfma: 0 = fp32 VALU kernel, 1 = r2 matrix-core kernel (3 workgroups per row group), 2 = the row-ring kernel (one workgroup per row group)
+static int stem_wgrad_groups(int B, int T, int S, int act_dtype, int* mfma) {
     const int To = T / 2, So = S / 4;
-    *mfma = act_dtype == MVIT_BF16 && So <= 112;
+    *mfma = act_dtype == MVIT_BF16 && So <= 112 ? 1 : 0;
     if (*mfma) {
         const int64_t nrows = (int64_t)B * To * So;
-        return (int)(nrows < 170 ? nrows : 170);          // x3 input channels = 510 workgroups (2 per CU by LDS)
+        if (stem_wgrad_v2() && (So & 7) == 0) {
+            *mfma = 2;
+            return (int)(nrows < 256 ? nrows : 256);
+        }
+        return (int)(nrows < 168 ? nrows : 168);          // x3 input channels = 504 workgroups (2 per CU by LDS); 168 = 8 x 21: whole XCDs
     }
     const int ntiles = B * To * ((So + 7) / 8) * ((So + 7) / 8);
     return ntiles < 512 ? ntiles : 512;
 }
 extern "C" int64_t mvit_stem_bwd_workspace_bytes(int B, int T, int S, int act_dtype) {
     if (B <= 0 || T <= 0 || S <= 0 || (T & 1) || (S & 3)) return 0;
-    bool mfma;
+    int mfma;
     const int groups = stem_wgrad_groups(B, T, S, act_dtype, &mfma);
     const int To = T / 2, So = S / 4;
     const int64_t pos_blocks = (So * So + 7) / 8;
@@ -298,13 +534,22 @@ extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, floa
     if ((T & 1) || (S & 3)) return MVIT_EUNSUPPORTED;
     hipStream_t st = as_stream(stream);
     const int To = T / 2, So = S / 4;
-    bool mfma;
+    int mfma;
     const int groups = stem_wgrad_groups(B, T, S, act_dtype, &mfma);
     const int pos_blocks = (So * So + 7) / 8;
     if (!workspace || workspace_bytes < mvit_stem_bwd_workspace_bytes(B, T, S, act_dtype)) return MVIT_EINVAL;
     float* wpart = workspace;                                   // per-workgroup slabs of dW, summed in workgroup order
     float* ppart = workspace + (int64_t)groups * 96 * 441;      // partial rows of dpos_temporal
-    if (mfma) {
+    if (mfma == 2) {
+        static DevFlags attr;
+        bool& done = dev_flag(attr);
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS) != hipSuccess)
+                return MVIT_ELAUNCH;
+            done = true;
+        }
+        hipLaunchKernelGGL(stem_wgrad_rows_kernel, dim3(groups), dim3(SG_NT), SG_LDS, st, clip, dx, B, T, S, To, So, wpart);
+    } else if (mfma) {
         hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(3 * groups), dim3(192), 0, st, clip, dx, dW, B, T, S, To, So, wpart);
     } else {
         const int tiles_x = (So + 7) / 8, tiles_y = (So + 7) / 8;

@@ -192,6 +192,19 @@ def main():
             _hip.check(L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(ps), _hip.ptr(pt), _hip.ptr(x), B, 16, 448, _hip.BF16, st))
         ms = timeit(fn, reps)
         print("stem B=%d: %.1f us  %.1f TFLOP/s  %.2f TB/s" % (B, ms * 1e3, B * 8.5e9 / ms / 1e9, (clip.numel() + x.numel()) * 4 / ms / 1e9))
+    elif op == "stembwd":
+        B = int(a[0]); reps = int(a[1]) if len(a) > 1 else 20
+        clip = torch.randn(B, 3, 16, 448, 448, device=dev)
+        dx = torch.randn(B, 8 * 112 * 112, 96, device=dev)
+        dW = torch.zeros(96, 441, device=dev)
+        dps, dpt = torch.zeros(112 * 112, 96, device=dev), torch.zeros(8, 96, device=dev)
+        nb = L.mvit_stem_bwd_workspace_bytes(B, 16, 448, _hip.BF16)
+        ws = torch.empty(nb // 4, device=dev)
+
+        def fn():
+            _hip.check(L.mvit_stem_bwd(_hip.ptr(clip), _hip.ptr(dx), _hip.ptr(dW), _hip.ptr(dps), _hip.ptr(dpt), B, 16, 448, _hip.BF16, _hip.ptr(ws), nb, st))
+        ms = timeit(fn, reps)
+        print("stem bwd (weight gradient + slab sum + position-embedding gradients) B=%d: %.1f us" % (B, ms * 1e3))
     elif op == "wgrad":
         M, N, K = int(a[0]), int(a[1]), int(a[2])
         reps = int(a[3]) if len(a) > 3 else 20
