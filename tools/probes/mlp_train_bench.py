@@ -1,7 +1,7 @@
-"""tools/mlp_train_bench.py M C [half] [reps]: the training forward of the MLP branch, fused (mvit_mlp_fused_train_fwd, + the pack it needs every
+"""(needs tools/probes/mlp_fused_train.patch applied) tools/probes/mlp_train_bench.py M C [half] [reps]: the training forward of the MLP branch, fused (mvit_mlp_fused_train_fwd, + the pack it needs every
 step) against the launches it replaces (fc1 + GELU with both 16-bit outputs, fc2 + residual).  Prints us per launch."""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from aicity_action_amd import _hip
 
 M, C = int(sys.argv[1]), int(sys.argv[2])
