@@ -370,7 +370,7 @@ def test_proj_maxpool_fused_skip_path_bwd(hip_lib, B, T, H, W, Cin, Cout):
     _close(dx1, ref, 1e-5)
 
 
-@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 2, 448)])
+@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 2, 448), (2, 16, 224)])      # the last: runs of 3-4 output rows per workgroup, across frames (row ring)
 def test_stem_bwd(hip_lib, B, T, S):
     clip = _rnd(B, 3, T, S, S, seed=25)
     w = _rnd(96, 3, 3, 7, 7, seed=26, scale=0.05).requires_grad_(True)

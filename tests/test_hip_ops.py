@@ -438,7 +438,7 @@ def test_proj_maxpool_fused_skip_path(hip_lib, B, T, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
-@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 16, 224)])
+@pytest.mark.parametrize("B,T,S", [(2, 4, 64), (1, 4, 56), (1, 16, 224), (4, 16, 224), (1, 8, 448)])      # the last two: workgroups walk runs of 2-4 tile-frames (frame ring)
 def test_stem(hip_lib, act, B, T, S):
     clip = _rnd(B, 3, T, S, S, seed=23)
     w = _rnd(96, 3, 3, 7, 7, seed=24, scale=0.05)

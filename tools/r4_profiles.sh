@@ -60,3 +60,27 @@ done
 cd $root
 (for shp in "50176 384" "18816 384" "200704 192" "802816 96"; do python3 tools/block_tail_bench.py $shp tail 20; python3 tools/block_tail_bench.py $shp mlp 20; done) 2>&1 | grep -v amdgpu > gpurun_out/${pre}_block_tail_alone.txt
 (for st in 1 2 3 4; do echo "HIP.STREAMS $st fwd fp16: $(python bench.py --mode fwd --streams $st --no-cpu-baseline --steps 40 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"; done) > gpurun_out/${pre}_fwd_streams.txt 2>&1
+# HBM traffic of the two stem kernels (PMC, separate passes)
+cd /tmp && export TMPDIR=/tmp
+rm -rf $root/gpurun_out/tt
+for op in stem stembwd; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/tt/f_$op -- python3 $root/tools/opbench.py $op 8 5 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/tt/w_$op -- python3 $root/tools/opbench.py $op 8 5 > /dev/null 2>&1
+done
+python3 - <<PY > $root/gpurun_out/${pre}_pmc_stem.txt
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$root/gpurun_out/tt/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        for k in ("stem_ring_kernel", "stem_wgrad_rows_kernel", "stem_pos_bwd_kernel", "slab_sum_kernel"):
+            if k in r["Kernel_Name"]:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("stem kernels, B = 8 16x448x448 (bf16 build), HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE KiB x 2: gfx950")
+print("tallies 128-B requests at 64 B); algorithmic: clip 308.3 MB fp32 + tokens 308.3 MB fp32 (forward: read + written; weight gradient: both read)")
+for k, d in acc.items():
+    f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"])) * 2048.0
+    w = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"])) * 1024.0
+    print("%-26s fetch %8.1f MB   write %8.1f MB   (n = %d / %d launches)" % (k, f / 1e6, w / 1e6, len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"])))
+PY
+rm -rf $root/gpurun_out/tt
+cd $root
