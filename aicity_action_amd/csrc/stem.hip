@@ -277,11 +277,12 @@ __global__ __launch_bounds__(256, 1) void stem_mfma_kernel(const float* __restri
 //   75 % for whole spatial tiles).
 //   K ordering: tap row rho = (dt * 3 + ci) * 7 + dy (63 rows + 1 zero row), 8 columns per row: column j is image pixel 4 xo - 4 + j,
 //   i.e. the zero weight sits in column 0 and the LDS image keeps the 16-byte ALIGNED quads of the clip as they are loaded (no shift).
-//   Fill: 7 pieces (16 B of fp32 -> 8 B of 16-bit) per lane and frame, at offsets computed once per kernel; the loads are buffer loads at
-//   UNCLAMPED offsets (outside the clip they return zero, outside the image but inside the clip they return a neighbour's pixels) and the
-//   out-of-image pieces are replaced by zero when the piece is converted -- no bounds test sits between a load and its use.
-//   The fp32 weights reach the B fragments through LDS (coalesced 16-byte loads, then 4-byte LDS gathers at a 441-word lane stride:
-//   conflict-free), instead of 256 strided 4-byte global loads per lane.
+//   Fill: wave 3 is a loader (see below): the two new frames of a tile-frame travel by LDS-DMA into an fp32 staging area one tile-frame
+//   ahead and are converted once into the ring (16 B of fp32 -> 8 B of 16 bit per piece, 28 pieces per lane and frame at offsets computed
+//   once per kernel); pieces outside the image request a valid dummy address and are replaced by zero when they are converted -- no
+//   bounds test sits between a request and its use.
+//   The fp32 weights reach the B fragments through LDS: converted once to 16 bit with coalesced 16-byte loads, then gathered with 2-byte
+//   LDS reads, instead of 256 strided 4-byte global loads per lane.
 //   Epilogue: the spatial position embedding of the tile's tokens stays in registers for the whole run over output frames.
 // ------------------------------------------------------------------------------------------------
 #define SR_PITCH 160                           // 68 pixels x 2 B = 136 -> 160: the two 16-lane halves of a fragment read hit disjoint banks
