@@ -238,6 +238,36 @@ def main():
         ntok = B * h * T * Ho * Wo
         print("pool B=%d h=%d THW=%dx%dx%d s=%d: %.1f us  %.2f Gtok/s  %.2f TB/s(out+in slice)" % (
             B, h, T, H, W, s, ms * 1e3, ntok / ms / 1e6, (ntok * 192 + B * h * T * H * W * 192) / ms / 1e9))
+    elif op == "poolkv":
+        B, h, T, H, W = (int(v) for v in a[:5])
+        reps = int(a[5]) if len(a) > 5 else 20
+        C = 96 * h
+        qkv = torch.randn(B, T * H * W, 3 * C, device=dev).bfloat16()
+        w = torch.randn(96, 27, device=dev) * 0.2
+        g, bt = torch.ones(96, device=dev), torch.zeros(96, device=dev)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(2, B, h, T * Ho * Wo, 96, device=dev, dtype=torch.bfloat16)
+
+        def pair():
+            _hip.check(L.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * C, C, _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt), _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt),
+                                                        _hip.ptr(out), None, None, B, h, T, H, W, 2, 1e-5, _hip.BF16, st))
+
+        def two():
+            for i in range(2):
+                _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * C, C * (1 + i), _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt), _hip.ptr(out[i]),
+                                                   B, h, T, H, W, 2, 1e-5, _hip.BF16, st))
+        print("pool k+v B=%d h=%d THW=%dx%dx%d stride 2: pair launch %.1f us, two launches %.1f us" % (B, h, T, H, W, timeit(pair, reps) * 1e3, timeit(two, reps) * 1e3))
+        # the same launch on inputs that are NOT cache-resident: a ring of buffers larger than the 256 MB memory-side cache
+        nbuf = max(2, int(600e6 // (qkv.numel() * 2)) + 1)
+        ring = [torch.randn_like(qkv) for _ in range(nbuf)]
+        k = [0]
+
+        def pair_cold():
+            q_ = ring[k[0] % nbuf]
+            k[0] += 1
+            _hip.check(L.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(q_), 3 * C, C, _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt), _hip.ptr(w), _hip.ptr(g), _hip.ptr(bt),
+                                                        _hip.ptr(out), None, None, B, h, T, H, W, 2, 1e-5, _hip.BF16, st))
+        print("   ... on a ring of %d input buffers (cold reads): pair launch %.1f us" % (nbuf, timeit(pair_cold, reps) * 1e3))
 
 
 if __name__ == "__main__":
