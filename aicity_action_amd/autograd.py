@@ -596,6 +596,21 @@ def _draw_train_noise(model, B, C_last, dev):
     return dp_all, mask
 
 
+def noise_from_keep(model, dp_keep, head_keep, dev):
+    """The (drop-path factors, head-dropout mask) pair of ``_draw_train_noise`` from GIVEN Bernoulli outcomes instead of fresh draws:
+    dp_keep [depth, 2, B] of {0,1} (the binarised floor(keep + U) of every DropPath call, common.py:46-59, in call order: attention
+    branch then MLP branch of each block), head_keep [B, C] of {0,1} (the elements nn.Dropout kept, head_helper.py:410-411).  The same
+    arithmetic as the drawing path: factor = kept / keep_i, mask = kept / (1 - p).  This is how a recorded step of the reference is
+    replayed (tests/golden/mvit_*_stoch.npz) -- the arithmetic downstream of the draws is what parity pins."""
+    dp_all = mask = None
+    if dp_keep is not None:
+        keep_all = torch.tensor([1.0 - g.drop_path for g in model.geoms], device=dev, dtype=torch.float32).view(-1, 1, 1)
+        dp_all = torch.as_tensor(dp_keep, device=dev).to(torch.float32) / keep_all
+    if head_keep is not None:
+        mask = torch.as_tensor(head_keep, device=dev).to(torch.float32) / (1.0 - model.head_dropout)
+    return dp_all, mask
+
+
 def _forward_train_one(model, clip, hx, dp_all, mask):
     pe = model.patch_embed.proj
     x = _StemFn.apply(clip, pe.weight, pe.bias, model.pos_embed_spatial, model.pos_embed_temporal, hx)
@@ -609,8 +624,10 @@ def _forward_train_one(model, clip, hx, dp_all, mask):
     return _HeadFn.apply(x, model.norm.weight, model.norm.bias, hp.weight, hp.bias, mask, hx)
 
 
-def forward_train(model, clip):
+def forward_train(model, clip, noise=None):
     """Forward in training mode (drop-path + head dropout active when model.training); returns raw logits.
+    ``noise`` = (drop-path factors [depth, 2, B] | None, head-dropout mask [B, C] | None) replaces the fresh draws (see
+    ``noise_from_keep``): used to replay a recorded stochastic step of the reference.
     Builds the autograd graph when grad mode is on.  With HIP.TRAIN_STREAMS > 1 (default 1: measured slower at B=8 @448, 78.7
     vs 72.4 ms in round 1 and 57.5 vs 49.2 ms in round 3 (profiles/r3_train_streams.txt) -- twice the launches and half-size weight-gradient GEMMs outweigh the filled tails) and >= 2 clips per stream the batch
     runs as sub-batches on side streams (forward and, through autograd's stream bookkeeping, backward): the kernels of one
@@ -620,7 +637,12 @@ def forward_train(model, clip):
     B = clip.shape[0]
     dev = clip.device
     assert list(clip.shape[2:]) == model.input_dims and clip.shape[1] == 3, "clip shape %s" % (tuple(clip.shape),)
-    dp_all, mask = _draw_train_noise(model, B, model.geoms[-1].dim_out, dev)
+    if noise is not None:
+        dp_all, mask = noise
+        assert dp_all is None or tuple(dp_all.shape) == (len(model.geoms), 2, B), "drop-path factors must be [depth, 2, B]"
+        assert mask is None or tuple(mask.shape) == (B, model.geoms[-1].dim_out), "head-dropout mask must be [B, C]"
+    else:
+        dp_all, mask = _draw_train_noise(model, B, model.geoms[-1].dim_out, dev)
     ns = model.train_streams
     if ns <= 1 or B < 2 * ns:
         return _forward_train_one(model, clip, hx, dp_all, mask)
@@ -643,8 +665,8 @@ def forward_train(model, clip):
     return torch.cat(outs, 0)
 
 
-def forward_with_grad(model, clip, return_logits=False):
-    logits = forward_train(model, clip)
+def forward_with_grad(model, clip, return_logits=False, noise=None):
+    logits = forward_train(model, clip, noise)
     if return_logits:
         return torch.softmax(logits, 1), logits
     if model.training and not model.use_act_in_train:

@@ -140,18 +140,23 @@ def attention(xn, thw, sd, pre, spec, taps=None):
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), out_thw  # :281
 
 
-def drop_path(z, p, training, gen=None):
-    """slowfast/models/common.py:46-59."""
+def drop_path(z, p, training, gen=None, keep_mask=None):
+    """slowfast/models/common.py:46-59.  ``keep_mask`` ([B] of {0,1}): the binarised draw floor(keep + U[B]) of one DropPath call,
+    injected (recovered from the reference by oracle/make_golden.py) instead of drawn here."""
     if p == 0.0 or not training:
         return z
     keep = 1 - p
-    mask = keep + torch.rand((z.shape[0],) + (1,) * (z.ndim - 1), dtype=z.dtype, generator=gen)
-    mask.floor_()
+    if keep_mask is not None:
+        mask = keep_mask.to(z.dtype).reshape((z.shape[0],) + (1,) * (z.ndim - 1))
+    else:
+        mask = keep + torch.rand((z.shape[0],) + (1,) * (z.ndim - 1), dtype=z.dtype, generator=gen)
+        mask.floor_()
     return z.div(keep) * mask
 
 
-def block(x, thw, sd, pre, spec, training=False, taps=None):
-    """MultiScaleBlock.forward (slowfast/models/attention.py:412-446), CHANNEL_EXPAND_FRONT variant."""
+def block(x, thw, sd, pre, spec, training=False, taps=None, dp_keep=None):
+    """MultiScaleBlock.forward (slowfast/models/attention.py:412-446), CHANNEL_EXPAND_FRONT variant.
+    dp_keep ([2, B] of {0,1}, optional): the block's two DropPath draws (attention branch :434, MLP branch :445), injected."""
     B, N, _ = x.shape
     xn = F.layer_norm(x, (spec.dim_in,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6)  # :421
     xb, thw_new = attention(xn, thw, sd, pre + "attn.", spec, taps)
@@ -163,11 +168,11 @@ def block(x, thw, sd, pre, spec, training=False, taps=None):
         t = x.reshape(B, thw[0], thw[1], thw[2], C).permute(0, 4, 1, 2, 3)
         t = F.max_pool3d(t, k, s, p)
         x = t.reshape(B, C, -1).transpose(1, 2)
-    x = x + drop_path(xb, spec.drop_path, training)    # :434
+    x = x + drop_path(xb, spec.drop_path, training, keep_mask=None if dp_keep is None else dp_keep[0])    # :434
     xn2 = F.layer_norm(x, (spec.dim_out,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6)  # :436
     hmid = F.gelu(F.linear(xn2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))  # common.py:27-28 (erf GELU)
     m = F.linear(hmid, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])           # common.py:31
-    x = x + drop_path(m, spec.drop_path, training)     # :445
+    x = x + drop_path(m, spec.drop_path, training, keep_mask=None if dp_keep is None else dp_keep[1])     # :445
     return x, thw_new
 
 
@@ -180,13 +185,16 @@ class _Spec(object):
 
 
 def forward(sd, clip, mv, patch=((3, 7, 7), (2, 4, 4), (1, 3, 3)), training=False,
-            head_act=True, taps=None, head_dropout=0.0):
+            head_act=True, taps=None, head_dropout=0.0, dp_keep=None, head_keep=None):
     """MViT.forward (slowfast/models/video_model_builder.py:1161-1335), non-cls, sep-pos-embed,
     TransformerBasicHead (slowfast/models/head_helper.py:409-417).
 
     sd: state-dict (350-key layout of SURVEY section 2.2), clip: [B,3,T,H,W] fp32, mv: MVIT cfg dict.
     Returns (output, logits): output = softmax(logits) in eval (head_act) or logits in train.
     taps (optional dict) is filled with intermediate tensors for golden fixtures.
+    Injected stochastic draws (training only): dp_keep [depth, 2, B] of {0,1} = the binarised DropPath draws in call order
+    (common.py:46-59; block i calls its DropPath twice), head_keep [B, C] of {0,1} = the kept elements of the head's
+    nn.Dropout(head_dropout) (head_helper.py:410-411: kept elements are scaled by 1/(1-p)).
     """
     kern, stride, pad = patch
     x = F.conv3d(clip, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"],
@@ -202,7 +210,7 @@ def forward(sd, clip, mv, patch=((3, 7, 7), (2, 4, 4), (1, 3, 3)), training=Fals
     specs = [_Spec(s, mv.get("Q_POOL_RESIDUAL", False)) for s in derive_specs(mv)]
     for i, spec in enumerate(specs):
         bt = {} if taps is not None else None
-        x, thw = block(x, thw, sd, "blocks.%d." % i, spec, training, bt)
+        x, thw = block(x, thw, sd, "blocks.%d." % i, spec, training, bt, None if dp_keep is None else dp_keep[i])
         if taps is not None:
             taps["block%d" % i] = x
             taps["thw%d" % i] = list(thw)
@@ -213,7 +221,10 @@ def forward(sd, clip, mv, patch=((3, 7, 7), (2, 4, 4), (1, 3, 3)), training=Fals
         taps["final_norm"] = x
     z = x.mean(1)                                                   # :1310
     if training and head_dropout > 0.0:
-        z = F.dropout(z, head_dropout, True)                        # head_helper.py:410-411
+        if head_keep is not None:
+            z = z * head_keep.to(z.dtype) * (1.0 / (1.0 - head_dropout))   # what F.dropout computes for a given Bernoulli mask
+        else:
+            z = F.dropout(z, head_dropout, True)                    # head_helper.py:410-411
     logits = F.linear(z, sd["head.projection.weight"], sd["head.projection.bias"])
     out = logits
     if head_act and not training:

@@ -72,6 +72,39 @@ def test_oracle_train_step_matches_reference_golden(name):
         assert np.abs(got - z["step." + k]).max() <= 2e-6, k
 
 
+@pytest.mark.parametrize("name", ["tiny_even_stoch", "tiny_odd_stoch", "tiny_plain_stoch", "full224_stoch"])
+def test_oracle_stochastic_train_step_matches_reference_golden(name):
+    """Row a11: a train step of the REAL reference with DROPPATH_RATE 0.4 / DROPOUT_RATE 0.5 on (oracle/make_golden_stoch.py).  The
+    fixture carries the reference's own draws (DropPath keeps per call, common.py:46-59; the head Dropout's kept elements,
+    head_helper.py:410-411); the restatement with those draws injected reproduces loss, logits and every clipped gradient."""
+    z, meta, cfg, sd, clip = _run(name, train=True)
+    assert cfg.MVIT.DROPPATH_RATE == 0.4 and cfg.MODEL.DROPOUT_RATE == 0.5
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    dp_keep, head_keep = torch.from_numpy(z["train.dp_keep"]), torch.from_numpy(z["train.head_keep"])
+    assert set(np.unique(z["train.dp_keep"])) == {0, 1} and dp_keep.shape == (len(z["train.dp_rates"]), 2, meta["batch"])
+    assert bool((dp_keep[0] == 1).all())                     # block 0 has nn.Identity (attention.py:349-351)
+    out, _ = O.forward(sd, clip, _mv(cfg), training=True, head_dropout=cfg.MODEL.DROPOUT_RATE, dp_keep=dp_keep, head_keep=head_keep)
+    loss = O.soft_target_cross_entropy(out, torch.from_numpy(z["train.labels"]))
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) <= 1e-6
+    assert np.abs(out.detach().numpy() - z["train.logits"]).max() <= 1e-5
+    tot = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values())).item()
+    assert abs(tot - float(z["train.grad_norm_fp64"])) <= 1e-5 * tot
+    coef = min(1.0, meta["clip"] / (float(z["train.grad_norm"]) + 1e-6))
+    for k, l2 in zip(meta["grad_keys"], z["train.grad_l2"]):
+        g = sd[k].grad * coef
+        gref = z["grad." + k]
+        assert np.abs(sample_like(g, z["gmom." + k]) - gref).max() <= 1e-5 * max(1.0, np.abs(gref).max()) + 1e-7, k
+        assert abs(float(g.double().norm()) - l2) <= 1e-5 * max(l2, 1e-3), k
+    # a sample dropped by a DropPath call contributes nothing to that branch's parameters: with EVERY sample of the batch dropped in
+    # block i's attention branch the gradient of that block's attention parameters is exactly zero
+    for i in range(dp_keep.shape[0]):
+        if int(dp_keep[i, 0].sum()) == 0:
+            assert float(sd["blocks.%d.attn.proj.weight" % i].grad.abs().max()) == 0.0
+        if int(dp_keep[i, 1].sum()) == 0:
+            assert float(sd["blocks.%d.mlp.fc2.weight" % i].grad.abs().max()) == 0.0
+
+
 def test_oracle_full224_train_step_matches_reference_golden():
     """BASELINE configs[0] geometry (all 16 blocks, real widths), one clip: loss, train-mode logits, gradient norm and every
     parameter's post-clip gradient samples of the REAL reference's train step (tests/golden/mvit_full224_train.npz) against
