@@ -805,7 +805,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
         // default: 64 queries per wave, one wave per SIMD (attention_w64.hip; +11 % on the model's shapes); MVIT_ATT_W64=0 selects the
         // 32-query kernels below, which also serve short sequences
         if (attn_fwd_prescales_q(Lq, Lk)) {
-            static DevFlags wattr_done_tab; bool& wattr_done = dev_flag(wattr_done_tab);
+            static DevFlags wattr_done_tab; DevFlag wattr_done = dev_flag(wattr_done_tab);
             if (!wattr_done) { const int rc = attn_fwd_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
             const int rc = attn_fwd_w64_launch(q, k, v, out, lse, B, heads, Lq, Lk, scale * 1.44269504088896340736f, add_q, st, ws);
             if (rc != MVIT_OK) return rc;
@@ -817,7 +817,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
             dim3 grid((Lq + A_QB - 1) / A_QB, B * heads);
             const float sl2 = scale * 1.44269504088896340736f;
             static const bool slot_env = getenv("MVIT_ATT_SLOT") && atoi(getenv("MVIT_ATT_SLOT")) != 0;
-            static DevFlags pattr_done_tab; bool& pattr_done = dev_flag(pattr_done_tab);
+            static DevFlags pattr_done_tab; DevFlag pattr_done = dev_flag(pattr_done_tab);
             if (!pattr_done) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AP_RING) != hipSuccess ||
@@ -837,7 +837,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
         const int NWr = nw_env == 8 ? 8 : 4;
         dim3 grid((Lq + 32 * NWr - 1) / (32 * NWr), B * heads);
         const float sl2 = scale * 1.44269504088896340736f;
-        static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+        static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, A_STAGES * A_TILEB) != hipSuccess ||

@@ -813,7 +813,7 @@ extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, 
 extern "C" int mvit_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
                                                   void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q, void* stream) {
     if (!q || !k || !v || !dout || !lse || !delta || !dq || Lk < 64 || Lq < 1) return MVIT_EINVAL;
-    static DevFlags done_tab; bool& done = dev_flag(done_tab);
+    static DevFlags done_tab; DevFlag done = dev_flag(done_tab);
     if (!done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; done = true; }
     const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, delta, dq, B, heads, Lq, Lk, scale, scale * 1.44269504088896340736f, add_q, as_stream(stream));
     if (rc != MVIT_OK) return rc;
@@ -869,14 +869,14 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         static const bool dq_w64_env = getenv("MVIT_ATT_DQ_W64") && atoi(getenv("MVIT_ATT_DQ_W64")) != 0;
         const bool dq_w64 = dq_w64_env && attn_fwd_prescales_q(Lq, Lk);      // (that kernel always rebuilds pre-scaled scores)
         if (dq_w64) {
-            static DevFlags wattr_done_tab; bool& wattr_done = dev_flag(wattr_done_tab);
+            static DevFlags wattr_done_tab; DevFlag wattr_done = dev_flag(wattr_done_tab);
             if (!wattr_done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
             const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, workspace, dq, B, heads, Lq, Lk, scale, sl2, add_q, st);
             if (rc != MVIT_OK) return rc;
             MVIT_LAUNCH_CHECK();
         }
         dim3 gq((Lq + 127) / 128, B * heads);
-        static DevFlags dq_attr_done_tab; bool& dq_attr_done = dev_flag(dq_attr_done_tab);
+        static DevFlags dq_attr_done_tab; DevFlag dq_attr_done = dev_flag(dq_attr_done_tab);
         if (!dq_attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
@@ -895,7 +895,7 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         else { if (pre) DQ_LAUNCH(false, true); else DQ_LAUNCH(false, false); }
 #undef DQ_LAUNCH
         MVIT_LAUNCH_CHECK();
-        static DevFlags dkv_attr_done_tab; bool& dkv_attr_done = dev_flag(dkv_attr_done_tab);
+        static DevFlags dkv_attr_done_tab; DevFlag dkv_attr_done = dev_flag(dkv_attr_done_tab);
         if (!dkv_attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess)

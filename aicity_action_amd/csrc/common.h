@@ -204,17 +204,48 @@ static inline bool side_join(SideStream* s, hipStream_t st) {
 
 // Lazily set per-kernel state (hipFuncSetAttribute for > 64 KiB of dynamic LDS, the CU count behind a persistent grid) is a property
 // of the DEVICE the call runs on, not of the process: one slot per device ordinal.
-struct DevFlags { bool f[16] = {}; };
-static inline bool& dev_flag(DevFlags& d) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return d.f[dev & 15];
+// Slots are atomics (two host threads driving two devices may race on first use; the worst case is a repeated, idempotent
+// hipFuncSetAttribute); an ordinal beyond the table, or a failing hipGetDevice, gets a scratch slot that is never cached -- the
+// attribute is then set on every launch instead of aliasing another device's "done" flag.
+#include <atomic>
+constexpr int MVIT_MAX_DEVS = 64;
+struct DevFlag {
+    std::atomic<bool>* slot;
+    bool scratch = false;
+    operator bool() const { return slot ? slot->load(std::memory_order_acquire) : false; }
+    DevFlag& operator=(bool v) { if (slot) slot->store(v, std::memory_order_release); return *this; }
+};
+struct DevFlags { std::atomic<bool> f[MVIT_MAX_DEVS] = {}; };
+static inline int dev_slot() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVIT_MAX_DEVS) return -1;
+    return dev;
 }
-struct DevInts { int v[16] = {}; };
-static inline int& dev_int(DevInts& d) {
+static inline DevFlag dev_flag(DevFlags& d) {
+    const int dev = dev_slot();
+    return DevFlag{dev >= 0 ? &d.f[dev] : nullptr};
+}
+struct DevInt {
+    std::atomic<int>* slot;
+    operator int() const { return slot ? slot->load(std::memory_order_acquire) : 0; }
+    DevInt& operator=(int v) { if (slot) slot->store(v, std::memory_order_release); return *this; }
+};
+struct DevInts { std::atomic<int> v[MVIT_MAX_DEVS] = {}; };
+static inline DevInt dev_int(DevInts& d) {
+    const int dev = dev_slot();
+    return DevInt{dev >= 0 ? &d.v[dev] : nullptr};
+}
+
+// CU count of the current device, cached per device ordinal; -1 on error
+static inline int dev_cu_count(DevInts& tab) {
+    DevInt c = dev_int(tab);
+    int n = c;
+    if (n > 0) return n;
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    return d.v[dev & 15];
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return -1;
+    c = n;
+    return n;
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -762,7 +762,7 @@ static int launch_linear_big_t(const void* a, int64_t lda, const void* w, const 
                                int K, int epi, hipStream_t st) {
     const int64_t nwg = ((M + G_BM - 1) / G_BM) * (N / G_BN);
     if (nwg > 0x7fffffff) return MVIT_EINVAL;
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<TO, RES, SCALE, DG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
@@ -1024,7 +1024,7 @@ static int launch_linear_pers_t(const void* a, int64_t lda, const void* w, const
     constexpr int BM = 64 * WM, SMEM = 2 * (BM * G_ROWB + G_PANEL_B);
     const int64_t nt = ((M + BM - 1) / BM) * (N / G_BN);
     if (nt > 0x7fffffff) return MVIT_EINVAL;
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pers_kernel<TO, GELU, WM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
@@ -1064,7 +1064,7 @@ static int launch_linear_mfma(const void* a, int64_t lda, const void* w, const f
     if (false && nwg2 >= 512 && sizeof(TA) == 2) {
         if (nwg2 > 0x7fffffff) return MVIT_EINVAL;
         constexpr int smem2 = 2 * LBM * L_ROWB + LBN * L_ROWB;   // 67584 >= stage (51200)
-        static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+        static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel<TA, TO, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess)

@@ -550,7 +550,7 @@ extern "C" int mvit_linear_wgrad(const void* a, int a_dtype, int64_t lda, const 
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, dim3(256), 0, st, (const float*)a, lda, (const float*)dy, ldd, row_scale,
                            rows_per_scale, dW, db, M, N, K, mchunk, part);
     } else if (p.path == 1) {
-        static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+        static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WB_SMEM) != hipSuccess)

@@ -221,14 +221,15 @@ static int k96_launch(const void* a, int64_t lda, const void* w, const float* bi
     constexpr int N = 96 * NWP * PASSES;
     constexpr int SMEM = N * K9_ROWB + 2 * K9_ABYTES;
     static DevInts ncu_tab;
-    int& ncu = dev_int(ncu_tab);
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-            return MVIT_ELAUNCH;
+    const int ncu = dev_cu_count(ncu_tab);
+    if (ncu <= 0) return MVIT_ELAUNCH;
+    static DevFlags attr_tab;
+    DevFlag attr_done = dev_flag(attr_tab);
+    if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_k96_kernel<NWP, PASSES, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM) != hipSuccess)
             return MVIT_ELAUNCH;
+        attr_done = true;
     }
     const int64_t ntiles = (M + K9_TILE_M - 1) / K9_TILE_M;
     const unsigned grid = (unsigned)(ntiles < ncu ? ntiles : ncu);

@@ -413,7 +413,7 @@ static int pp_launch(const void* a, int64_t lda, const void* w, const float* bia
                      const float* row_scale, int64_t rps, void* y, void* y2, int64_t ldy, int64_t M, int N, int K, hipStream_t st) {
     const int smem = PP_TILES_BYTES + 4 * N;
     static DevInts attr_tab;
-    int& attr_smem = dev_int(attr_tab);
+    DevInt attr_smem = dev_int(attr_tab);
     if (smem > attr_smem) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_pp_kernel<EPI, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return MVIT_ELAUNCH;
@@ -422,12 +422,8 @@ static int pp_launch(const void* a, int64_t lda, const void* w, const float* bia
     const int64_t nt = ((M + PP_BM - 1) / PP_BM) * (N / PP_BN);
     const int64_t q = (nt + 7) / 8;
     static DevInts ncu_tab;
-    int& ncu = dev_int(ncu_tab);
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8)
-            return MVIT_ELAUNCH;
-    }
+    const int ncu = dev_cu_count(ncu_tab);
+    if (ncu < 8) return MVIT_ELAUNCH;
     const int per_xcd = ncu / 8;
     const int per = (int)(q < per_xcd ? q : per_xcd);         // one workgroup per CU (32 CUs per XCD on MI355X)
     hipLaunchKernelGGL((linear_pp_kernel<EPI, TO>), dim3((unsigned)(8 * per)), dim3(512), smem, st, (const bf16_t*)a, lda, (const bf16_t*)w,

@@ -908,7 +908,7 @@ static int mf_launch(const float* x, const void* o, const void* packed, const fl
     const int ring = 6 * K::WU + K::B1BYTES + (PROJ ? K::BPBYTES : 0), stage = 4 * K::ST_PITCH + 12 * K::C;       // rings + biases | staging areas (+ b2, gamma, beta of the emitted LayerNorm)
     const int smem = ring > stage ? ring : stage;
     static DevFlags attr_tab;
-    bool& attr_done = dev_flag(attr_tab);
+    DevFlag attr_done = dev_flag(attr_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<CB, TB, PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return MVIT_ELAUNCH;

@@ -477,7 +477,7 @@ static int launch_pool_tiled(const void* qkv, int64_t ld, int chan_off, const fl
     using P = PoolTile<TA, S>;
     const int nset = w2 ? 2 : 1;
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
@@ -497,7 +497,7 @@ static int launch_pool_tiled_bwd(const void* qkv, int64_t ld, int chan_off, cons
                                  hipStream_t st) {
     using P = PoolTile<TA, S>;
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, S, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)
@@ -704,7 +704,7 @@ static int launch_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
     constexpr int SM = P::IN_BYTES + 3 * P::NTOK * 96 * (int)sizeof(TA);
     static_assert(SM >= 2592 * 4, "partial row must fit");
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_tiled_kernel<TA, S>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess)
@@ -871,7 +871,7 @@ static int launch_pool_dgrad2_tiled(const void* dconv, const float* w, void* dqk
     using P = Dgrad2Tile<TA>;
     const int nset = w2 ? 2 : 1;
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), nset * B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_dgrad2_tiled_kernel<TA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 P::SMEM) != hipSuccess)
@@ -899,7 +899,7 @@ static int launch_pool_dgrad_tiled(const void* dconv, const float* w, void* dqkv
                                    int H, int W, hipStream_t st) {
     using P = PoolTile<TA, 1>;
     dim3 grid(((W + P::XO - 1) / P::XO) * ((H + P::ROWS - 1) / P::ROWS), B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_tiled_kernel<TA, 1, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, P::SMEM) != hipSuccess)

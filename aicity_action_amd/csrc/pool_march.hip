@@ -271,7 +271,7 @@ static int launch_march(const void* in, int64_t ld, int chan_off, const float* w
                         int out_chan_off, int out_heads, hipStream_t st) {
     using P = March<TA, S>;
     dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_march_kernel<TA, S, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 P::SMEM) != hipSuccess)

@@ -217,7 +217,7 @@ extern "C" int mvit_proj_maxpool_fwd(const float* x, const void* w, const float*
 #define SF_GO(IDX_, NK_) { \
         constexpr int smem = NK_ * SP_ROWS * SP_ROWB + SP_ROWS * SF_LD * 4; \
         if (smem > 65536) { \
-            static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab); \
+            static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab); \
             if (!attr_done) { \
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_maxpool_kernel<IDX_, NK_>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) \
                     return MVIT_ELAUNCH; \

@@ -644,7 +644,7 @@ extern "C" int mvit_stem_fwd(const float* clip, const float* w, const float* bia
             return MVIT_OK;
         }
         static DevFlags attr;
-        bool& done = dev_flag(attr);
+        DevFlag done = dev_flag(attr);
         if (!done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SR_LDS) != hipSuccess)
                 return MVIT_ELAUNCH;

@@ -542,7 +542,7 @@ extern "C" int mvit_stem_bwd(const float* clip, const float* dx, float* dW, floa
     float* ppart = workspace + (int64_t)groups * 96 * 441;      // partial rows of dpos_temporal
     if (mfma == 2) {
         static DevFlags attr;
-        bool& done = dev_flag(attr);
+        DevFlag done = dev_flag(attr);
         if (!done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS) != hipSuccess)
                 return MVIT_ELAUNCH;

@@ -254,7 +254,7 @@ bool mvit_internal_wgrad_pp_plan(int64_t lda, int64_t ldd, int64_t M, int N, int
 
 int mvit_internal_wgrad_pp(const void* a, int64_t lda, const void* dy, int64_t ldd, float* part, int64_t M, int N, int K, int64_t nch, int mchunk,
                            int do_bias, hipStream_t st) {
-    static DevFlags attr_done_tab; bool& attr_done = dev_flag(attr_done_tab);
+    static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WP_SMEM) != hipSuccess)
             return MVIT_ELAUNCH;

@@ -306,6 +306,9 @@ def eval_epoch(val_loader, model, val_meter, cur_epoch, cfg):
         val_meter.update_predictions(preds, labels)
         val_meter.log_iter_stats(cur_epoch, cur_iter)
         val_meter.iter_tic()
+    core = _unwrap(model)
+    if hasattr(core, "check_finite"):
+        core.check_finite()                              # fp16 guard of HIP.PRECISION auto (the epoch log below synchronises anyway)
     result = val_meter.log_epoch_stats(cur_epoch)
     val_meter.reset()
     return result
@@ -327,6 +330,10 @@ def perform_test(test_loader, model, test_meter, cfg):
         test_meter.update_stats(preds, labels, video_idx)
         test_meter.log_iter_stats(cur_iter)
         test_meter.iter_tic()
+    test_meter.flush()                                   # every batch's scores are on the host (a non-finite one raises in TestMeter._apply)
+    core = _unwrap(model)
+    if hasattr(core, "check_finite"):
+        core.check_finite()                              # the fp16 guard of HIP.PRECISION auto: raised by THIS call, not by a later forward
     return test_meter.finalize_metrics()
 
 

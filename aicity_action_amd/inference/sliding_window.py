@@ -97,6 +97,10 @@ class SlidingWindowClassifier(object):
         core = self.model.module if hasattr(self.model, "module") else self.model
         if hasattr(core, "check_finite"):
             core.check_finite()                # (the copy above has synchronised: no extra wait) fp16 overflow under HIP.PRECISION auto raises here
+        if not np.isfinite(probs).all():       # whatever the arithmetic: the scores are on the host now, a non-finite one never leaves this call
+            raise FloatingPointError("SlidingWindowClassifier: non-finite scores for %d of %d windows (HIP.PRECISION %s); pin HIP.PRECISION bf16 "
+                                     "or fp32 for this checkpoint" % (int((~np.isfinite(probs).all(1)).sum()), len(probs),
+                                                                      getattr(getattr(core.cfg, "HIP", None), "PRECISION", "auto")))
         out = [(t0, t1, probs[k].astype(np.float32)) for k, (t0, t1) in enumerate(windows)]
         out.sort(key=lambda x: x[0])
         return out

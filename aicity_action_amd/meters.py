@@ -381,6 +381,8 @@ class TestMeter(_IterClock):
         self._absorb(wait=True)
 
     def _apply(self, preds, labels, clip_ids):
+        if not bool(torch.isfinite(preds).all()):       # host data by now: the check is free, and a NaN score must not be summed into a video
+            raise FloatingPointError("TestMeter: non-finite clip scores (fp16 overflow under HIP.PRECISION auto? pin HIP.PRECISION bf16)")
         vid = torch.div(clip_ids, self.num_clips, rounding_mode="floor")
         seen = self.video_labels[vid] > 0                                   # a label already on file must not change
         assert torch.equal(self.video_labels[vid][seen], labels[seen]), "clips of one video disagree on its label"

@@ -13,6 +13,7 @@ library raises.
 """
 import math
 import os
+import weakref
 from functools import partial
 
 import torch
@@ -89,6 +90,7 @@ def _unsupported(cond, what):
 
 
 # the fused block tail (csrc/mlp_fused.hip) for the inference forward; MVIT_MLP_FUSE=0 keeps LayerNorm + fc1 + fc2 as three launches (A/B runs)
+_FINITE_GUARDS = weakref.WeakKeyDictionary()     # model -> (device flag, event) of its last unchecked eval forward(s) under HIP.PRECISION auto
 _MLP_FUSE = os.environ.get("MVIT_MLP_FUSE", "1") != "0"
 # ... with the attention output projection in front of it (mvit_block_tail_fwd); MVIT_TAIL_FUSE=0 keeps proj as its own launch
 _TAIL_FUSE = os.environ.get("MVIT_TAIL_FUSE", "1") != "0"
@@ -295,7 +297,10 @@ class MViT(nn.Module):
             e[3] = e[0]._version
 
     def forward(self, x, bboxes=None, dataset_name=None, run_cross_proj=False, use_moco=False, moco_momentum=0.9,
-                return_logits=False):
+                return_logits=False, noise=None):
+        """``noise`` (training path only; not part of the reference's signature): (drop-path factors [depth, 2, B] | None,
+        head-dropout mask [B, C] | None) used INSTEAD of fresh draws -- autograd.noise_from_keep builds it from recorded Bernoulli
+        outcomes; it passes through a DistributedDataParallel wrap as a keyword."""
         if not self.direct_input:
             x = x[0]                                                 # :1165-1167
         if not x.is_cuda:
@@ -304,7 +309,9 @@ class MViT(nn.Module):
             # fp16 training needs loss scaling: solver.HipGradScaler (engine.train enables it for TRAIN.MIXED_PRECISION)
             # training path: keeps activations, drop-path / dropout active, hand-written backward (autograd.py)
             from ..autograd import forward_with_grad
-            return forward_with_grad(self, x, return_logits)
+            return forward_with_grad(self, x, return_logits, noise)
+        if noise is not None:
+            raise ValueError("MViT: `noise` applies to the training path only (drop-path / dropout are identities in inference)")
         self._raise_if_flagged(block=False)                 # the previous call's output, if its check has completed by now
         ns = min(self.eval_streams, x.shape[0] // 2)        # at least two clips per sub-batch
         out = self._forward_streams(x, return_logits, ns) if ns > 1 else self._forward_hip(x, return_logits)
@@ -318,18 +325,26 @@ class MViT(nn.Module):
     # and half has a finite range (65504): activations of a trained model far outside the range seen at random initialisation
     # would overflow silently.  Every eval forward therefore leaves ONE device scalar (the sum of its output: non-finite iff any
     # element is) and an event; the flag is read without blocking at the next forward and, blocking, by check_finite() -- which
-    # the sliding-window classifier calls where it synchronises anyway.  No host sync is added to the forward itself.
+    # the sliding-window classifier and the test loop call where they synchronise anyway (inference/sliding_window.py::run,
+    # engine.perform_test / eval_epoch: the callers that are about to read the scores raise in the SAME call; a bare ``model([x])``
+    # defers to the next forward or to ``check_finite()``).  A flag that has not been read when the next forward runs is ADDED to that
+    # forward's flag (a NaN / inf stays one), so no batch of a loop is ever dropped from the check.  No host sync is added to the
+    # forward itself.  The (flag, event) pair lives in a weak-keyed table outside the module: ``copy.deepcopy`` / pickling of a model
+    # after an eval forward never meet a torch.cuda.Event.
     def _flag_output(self, out):
         ev = torch.cuda.Event()
         flag = out.float().sum()
+        prev = _FINITE_GUARDS.get(self)
+        if prev is not None:            # a flag nobody has read yet (its event had not completed at this forward): carried along, not dropped
+            flag = flag + prev[0]
         ev.record()
-        self._finite_guard = (flag, ev)
+        _FINITE_GUARDS[self] = (flag, ev)
 
     def _raise_if_flagged(self, block):
-        g = getattr(self, "_finite_guard", None)
+        g = _FINITE_GUARDS.get(self)
         if g is None or (not block and not g[1].query()):
             return
-        self._finite_guard = None
+        del _FINITE_GUARDS[self]
         if not bool(torch.isfinite(g[0]).item()):
             raise FloatingPointError(
                 "MViT (HIP path): non-finite output from the fp16 inference arithmetic that HIP.PRECISION 'auto' selects "

@@ -55,16 +55,15 @@ def self_launch(n):
     """`bench.py --gpus N` without an external launcher: run torch.distributed.run with N ranks as a CHILD process (this process has
     not imported torch and never touches the GPU, so nothing is exec'ed over an initialised HIP runtime) and hand back its return
     code; the ranks inherit stdout / stderr, so rank 0's JSON line is this command's JSON line."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")                  # torch.distributed.run would set 1 (and warn); the CPU legs are rank-0, N = 1 only
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher itself picks AND HOLDS the rendezvous port (c10d store on port 0), so no other process can take it
+    # between choosing and binding (a bind-close-reuse of a "free" port raced on shared boxes); --local-addr pins MASTER_ADDR to
+    # 127.0.0.1 (the container hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--standalone", "--local-addr", "127.0.0.1",
+           os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -216,11 +215,19 @@ def main():
         ev_ms = iv[len(iv) // 2]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     per_rank = [{"rank": 0, "device": dev_index, "ms_per_step": round(dt / args.steps * 1e3, 4)}]
+    allreduce_ok = None
     if world > 1:
+        ones = torch.ones(8, device=dev)
+        dist.all_reduce(ones)                      # every rank contributes: the sum must be the world size the launcher asked for
+        allreduce_ok = bool((ones == float(world)).all().item())
+        assert allreduce_ok, "all-reduce of ones gave %s on world size %d" % (ones.tolist(), world)
         mine = torch.tensor([dt, float(dev_index)], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [{"rank": i, "device": int(e[1].item()), "ms_per_step": round(e[0].item() / args.steps * 1e3, 4)} for i, e in enumerate(every)]
+    for r_ in per_rank:                            # what each rank did on its own clock (the headline uses the slowest rank's time for all)
+        r_["clips_per_s"] = round((n_windows / world if args.mode == "window" else args.batch) / (r_["ms_per_step"] * 1e-3), 2)
+    if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     assert torch.isfinite(out).all()
@@ -306,7 +313,9 @@ def main():
 
         def rl(name, tot_flops, tot_ms, per_block, traffic=None):
             ach = tot_flops / (tot_ms * 1e-3) / 1e12
-            return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            return {"kernel": name, "timed": "alone, randn operands, back to back on the launch stream (the in-step figure is in profiles/: kernels run "
+                                             "5-10 % slower between the step's other launches)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": clips_pl, "avg_launch_ms": round(tot_ms / len(flops), 4),
                     "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
         sfx = args.precision if act else "f32"
@@ -498,6 +507,7 @@ def main():
                                "unit": "TFLOP/s", "frac": round(clips_per_s / world * gf / 1e3 / peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
             "world_size": dist.get_world_size() if world > 1 else 1,      # as the process group saw it
+            "allreduce_of_ones_ok": allreduce_ok,
             "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
             "ranks": per_rank, "ms_per_step_rank_min": min(r_["ms_per_step"] for r_ in per_rank),
             "ms_per_step_rank_max": max(r_["ms_per_step"] for r_ in per_rank),

@@ -11,6 +11,14 @@ Parity status:
     of OpenCV's published 8-bit bilinear algorithm (opencv/modules/imgproc/src/resize.cpp, 4.x: 11-bit fixed-point
     coefficients, horizontal pass in int, vertical pass ((b0*(S0>>4))>>16)+((b1*(S1>>4))>>16)+2)>>2).  PARITY UNPINNED
     for this step: no golden vector from a real cv2 could be produced here.
+  * exact 2x decimation (an 896 x 896 ROI -> 448): cv2.resize switches INTER_LINEAR to INTER_AREA there (resize.cpp, resize():
+    ``if (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA``, with the
+    comment that the two are equal).  They ARE equal in the 8-bit path, so no second code path is needed: at 2x the bilinear
+    coefficients are 1024 / 1024 exactly ((d + .5) * 2 - .5 = 2d + .5), the horizontal pass gives S = 1024 (a + b), and
+    ((1024 * (S >> 4)) >> 16) = a + b without any truncation, so the result is (a + b + c + d + 2) >> 2 -- which is what the
+    INTER_AREA fast path computes for uchar (ResizeAreaFastVec: (S[0] + S[1] + nextS[0] + nextS[1] + 2) >> 2).
+    ``resize_area_fast_2x_u8`` below restates that path; tests/test_inference_cpu.py and tests/test_hip_inference.py assert the
+    equality for the restatement and for the HIP kernel.  (Other integer decimation factors do NOT switch: only 2 x 2.)
 """
 import numpy as np
 import torch
@@ -64,6 +72,37 @@ def resize_linear_u8(img, dst_h, dst_w):
     b1 = ya[:, 1][:, None, None]
     out = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize_area_fast_2x_u8(img):
+    """OpenCV INTER_AREA fast path for an exact 2 x 2 decimation of uint8 (resize.cpp, ResizeAreaFast_Invoker / ResizeAreaFastVec,
+    scale 2): out = (a + b + c + d + 2) >> 2 over each 2 x 2 cell -- the path cv2.resize(..., INTER_LINEAR) takes at this scale."""
+    H, W, C = img.shape
+    assert H % 2 == 0 and W % 2 == 0
+    s = img.astype(np.int32)
+    return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+
+def resize_bilinear_float(img, dst_h, dst_w):
+    """Independent cross-check (NOT OpenCV's arithmetic): bilinear interpolation with half-pixel centres in float64, edge-clamped,
+    rounded to nearest.  OpenCV's 11-bit fixed-point result stays within 1 LSB of it."""
+    H, W, C = img.shape
+
+    def axis(src, dst):
+        f = (np.arange(dst) + 0.5) * (src / dst) - 0.5
+        s = np.floor(f).astype(np.int64)
+        w = f - s
+        w = np.where(s < 0, 0.0, w)
+        s = np.maximum(s, 0)
+        w = np.where(s >= src - 1, 0.0, w)
+        s = np.minimum(s, src - 1)
+        return s, np.minimum(s + 1, src - 1), w
+    y0, y1, wy = axis(H, dst_h)
+    x0, x1, wx = axis(W, dst_w)
+    a = img.astype(np.float64)
+    top = a[y0][:, x0] * (1 - wx)[None, :, None] + a[y0][:, x1] * wx[None, :, None]
+    bot = a[y1][:, x0] * (1 - wx)[None, :, None] + a[y1][:, x1] * wx[None, :, None]
+    return top * (1 - wy)[:, None, None] + bot * wy[:, None, None]
 
 
 def preprocess_window(frames_u8, idxs, size, mean=0.45, std=0.225):

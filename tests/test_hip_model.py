@@ -188,6 +188,7 @@ def test_logit_gate_over_seeds_and_a_trained_like_model():
     from aicity_action_amd.config import load_config
     from aicity_action_amd.utils.synth import stress_state_dict
     worst = {"fp16": 0.0, "bf16": 0.0}
+    stressed_abs = {}
     rows = []
     for c in _gate_cases():
         ref = np.array(c["logits"], np.float32).reshape(1, -1)
@@ -204,7 +205,10 @@ def test_logit_gate_over_seeds_and_a_trained_like_model():
                 assert ran == ("fp16" if prec == "auto" else "bf16")
                 probs, logits = model._forward_hip(clip, return_logits=True)
             scale = max(1.0, float(np.abs(ref).max())) if c["stressed"] else 1.0
-            errs[ran] = float(np.abs(logits.float().cpu().numpy() - ref).max()) / scale
+            abs_err = float(np.abs(logits.float().cpu().numpy() - ref).max())
+            errs[ran] = abs_err / scale
+            if c["stressed"]:
+                stressed_abs[ran] = (abs_err, scale)
             if prec == "auto":
                 perr = float(np.abs(probs.float().cpu().numpy() - np.array(c["probs"], np.float32).reshape(1, -1)).max())
             del model
@@ -216,6 +220,13 @@ def test_logit_gate_over_seeds_and_a_trained_like_model():
         print(" %4d  %5d %5d %8s   %.3e        %.3e        %.3e" % r_)
     print("worst fp16 %.3e (gate 1e-3)   worst bf16 %.3e (reported: bf16 storage cannot meet the gate)" % (worst["fp16"], worst["bf16"]))
     assert worst["fp16"] <= 1e-3
+    # the stressed (trained-like) case separately, in ABSOLUTE terms: its gate above is relative to max|logit| (~5.8), i.e. it allows
+    # ~5.8e-3 absolute.  The absolute figure is recorded and bounded on its own (2.5e-3: half-precision storage of activations that
+    # are ~6x larger than at initialisation), so the README / DESIGN can quote both numbers instead of folding them into one.
+    a16, sc = stressed_abs["fp16"]
+    print("stressed model: fp16 ABSOLUTE logit error %.3e (max |logit| %.2f -> relative %.3e); bf16 absolute %.3e"
+          % (a16, sc, a16 / sc, stressed_abs["bf16"][0]))
+    assert a16 <= 2.5e-3
 
 
 def test_fp16_auto_inference_raises_on_non_finite_output():
@@ -244,3 +255,74 @@ def test_fp16_auto_inference_raises_on_non_finite_output():
             else:
                 model.check_finite()
     assert not torch.isfinite(outs["auto"]).all() and torch.isfinite(outs["bf16"]).all()
+
+
+def test_fp16_guard_raises_in_the_same_call_for_callers_that_read_the_scores():
+    """A bare ``model([x])`` defers the non-finite check (no host sync in the forward); the callers that read the scores anyway raise
+    in the SAME call: SlidingWindowClassifier.run and engine.perform_test.  A flag that was not read before the next forward is carried
+    along (overflowing batch first, a finite batch right behind it with no synchronisation in between: check_finite still raises), and
+    a model that has run an eval forward can be deep-copied (the guard's event lives outside the module)."""
+    import copy
+    from aicity_action_amd import engine
+    from aicity_action_amd.inference import SlidingWindowClassifier
+    z, meta = load_golden("tiny_even")
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    cfg = cfg_for_case(meta, "auto")
+    cfg.NUM_GPUS = 1
+    good = build_model(cfg).eval()
+    load_synth_weights(good, meta["weight_seed"])
+    bad = copy.deepcopy(good)
+    with torch.no_grad():
+        bad.blocks[1].mlp.fc2.weight.mul_(3.0e5)
+        good([clip])
+        copy.deepcopy(good)                                        # after an eval forward under auto
+        good.check_finite()
+        # overflow, then -- no sync -- a finite forward of the SAME model object: the first flag must survive
+        w = bad.blocks[1].mlp.fc2.weight
+        saved = w.detach().clone()
+        bad([clip])
+        w.copy_(saved / 3.0e5)
+        bad([clip])
+        with pytest.raises(FloatingPointError):
+            bad.check_finite()
+        w.copy_(saved)
+    frames = torch.randint(0, 256, (40, 54, 96, 3), device="cuda", dtype=torch.uint8)
+    swc = SlidingWindowClassifier(bad, frame_length=4, frame_stride=4, proposal_length=16, proposal_stride=8, frame_size=64, batch_size=2)
+    with pytest.raises(FloatingPointError):
+        swc.run(frames)
+    assert len(SlidingWindowClassifier(good, frame_length=4, frame_stride=4, proposal_length=16, proposal_stride=8, frame_size=64,
+                                       batch_size=2).run(frames)) == 5
+    loader = [([clip], torch.tensor([1, 1]).cuda(), torch.tensor([0, 1]).cuda(), {})] * 2
+    with pytest.raises(FloatingPointError):
+        engine.perform_test(loader, bad, engine.TestMeter(num_videos=1, num_clips=2, num_cls=cfg.MODEL.NUM_CLASSES, overall_iters=2), cfg)
+    with torch.no_grad():
+        good([clip])                                                # the guard state of `bad` does not leak into other models
+    good.check_finite()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_block_forward_wiring_under_every_fuse_switch(prec, monkeypatch):
+    """The A/B switches of the inference block (MVIT_TAIL_FUSE / MVIT_MLP_FUSE / MVIT_LN1_FUSE are read once at import, so the model
+    tests only ever run the default combination): patched here on the module, a tiny model (widths 96 / 192 / 384: all three fused
+    kernels apply) must give the same logits through every path -- fused tail == proj launch + fused MLP == four launches within the
+    16-bit bound, including the path that hands the next block's norm1 over from the tail (`u`)."""
+    from aicity_action_amd.models import mvit as M
+    z, meta = load_golden("tiny_even")
+    cfg, model = _build(meta, prec)
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    outs = {}
+    for tail, mlp, ln1 in ((1, 1, 0), (1, 1, 1), (0, 1, 0), (0, 0, 0)):
+        monkeypatch.setattr(M, "_TAIL_FUSE", bool(tail))
+        monkeypatch.setattr(M, "_MLP_FUSE", bool(mlp))
+        monkeypatch.setattr(M, "_LN1_FUSE", bool(ln1))
+        model._bf16_cache.clear()                         # packed images are cached per weight version, not per switch
+        with torch.no_grad():
+            outs[(tail, mlp, ln1)] = model._forward_hip(clip, return_logits=True)[1].float().clone()
+    ref = torch.from_numpy(z["logits"]).cuda()
+    tol = 2e-2 if prec == "bf16" else 3e-3
+    for key, lg in outs.items():
+        assert (lg - ref).abs().max().item() <= tol, (key, (lg - ref).abs().max().item())
+    # (the tail takes the next block's LayerNorm from its accumulators in another summation order than ln_fwd_kernel: close, not bitwise)
+    spread = max((a - outs[(1, 1, 0)]).abs().max().item() for a in outs.values())
+    print("[%s] logits spread over the fuse switches %.2e" % (prec, spread))
+    assert spread <= tol

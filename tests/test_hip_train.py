@@ -366,7 +366,9 @@ def test_eval_mode_backward_with_auto_precision_keeps_one_arithmetic():
         load_synth_weights(model, 11)
         with torch.no_grad():                    # an inference call first: under "auto" it builds the fp16 weight copies
             model([clip.cuda()])
-        assert model.precision == ("bf16" if prec == "bf16" else "bf16")     # grad mode on + trainable parameters
+        assert model.precision == "bf16"         # grad mode on + trainable parameters: "auto" resolves to the training arithmetic
+        with torch.no_grad():
+            assert model.precision == ("fp16" if prec == "auto" else "bf16")     # ... and to the gate-passing fp16 build for inference
         probs, lg = model([clip.cuda()], return_logits=True)
         (lg * w.cuda()).sum().backward()
         grads[prec] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}

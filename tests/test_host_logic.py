@@ -185,7 +185,7 @@ def test_no_weight_decay_grouping_follows_the_module_name_rule():
 
 def test_bench_self_launch_builds_the_launcher_command_without_touching_the_gpu(monkeypatch):
     """bench.py --gpus N without WORLD_SIZE: the parent must only start `python -m torch.distributed.run ... bench.py <same args>` as a
-    child (127.0.0.1, a free port, N ranks) and return its code -- it must not import torch (an exec / fork of a process that has
+    child (--standalone on 127.0.0.1, N ranks) and return its code -- it must not import torch (an exec / fork of a process that has
     initialised HIP takes the machine down on this pool)."""
     import importlib.util
     import subprocess
@@ -209,6 +209,7 @@ def test_bench_self_launch_builds_the_launcher_command_without_touching_the_gpu(
     assert ex.value.code == 7                                  # the launcher's return code is bench.py's
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    # the launcher picks and holds its own rendezvous port (no bind-close-reuse race), on 127.0.0.1
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
