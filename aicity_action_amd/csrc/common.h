@@ -248,6 +248,25 @@ static inline int dev_cu_count(DevInts& tab) {
     return n;
 }
 
+// An LDS pointer made opaque to the optimiser (keeps loop-invariant reads INSIDE a loop instead of pinning dozens of registers)
+// WITHOUT losing its address space: the usual `asm volatile("" : "+v"(ptr))` on a generic pointer cuts the trace back to the
+// __shared__ array, and every read through it becomes a FLAT load -- counted in vmcnt AND lgkmcnt and only completed by
+// `s_waitcnt vmcnt(0)`, i.e. it also waits for every global load / LDS-DMA / store the wave has in flight (found in the pooling
+// kernels in round 5: each frame's weight reads waited for the NEXT frame's prefetch).  Launder the 32-bit LDS offset instead.
+#ifdef __HIPCC__
+typedef const __attribute__((address_space(3))) char* lds_cptr_t;
+typedef float lds_f32x2_t __attribute__((ext_vector_type(2)));       // (HIP's float2 class cannot be copied out of an address-space-3 object)
+__device__ __forceinline__ lds_cptr_t lds_opaque(const void* p) {
+    uint32_t a = (uint32_t)(uintptr_t)(lds_cptr_t)(const char*)p;
+    asm volatile("" : "+v"(a));
+    return (lds_cptr_t)(uintptr_t)a;
+}
+template <typename T>
+__device__ __forceinline__ T lds_ld(lds_cptr_t p, int byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>(p + byte_off);
+}
+#endif
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // deterministic column sums of a [nparts][width] fp32 partial table (backward_rowops.hip)

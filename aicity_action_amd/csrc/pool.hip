@@ -425,8 +425,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
         if (P::DB && f + 1 < T) prefetch(f + 1);
         const int cur = P::DB ? (f & 1) : 0;
         const TA* tile = reinterpret_cast<const TA*>(smem + cur * P::IN_BYTES) + 2 * cp;
-        const float* wm = wmine;
-        asm volatile("" : "+v"(wm));   // keep the 54 weight reads inside the loop (LICM would pin 54 VGPRs)
+        const lds_cptr_t wm = lds_opaque(wmine);   // keep the 54 weight reads inside the loop (LICM would pin 54 VGPRs), as LDS reads
 #pragma unroll 1
         for (int dy = 0; dy < ((POOL_ABL & 1) ? 0 : 3); ++dy) {
             float xin[P::IW][2];
@@ -438,7 +437,7 @@ __global__ __launch_bounds__(S == 1 ? 384 : 192, 3) void pool_tiled_kernel(
                 // input frame f is tap dt of output frame f + 1 - dt  -> accumulator set 2 - dt
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const float2 wv = *reinterpret_cast<const float2*>(wm + ((dt * 3 + dy) * 3 + dx) * 96);
+                    const lds_f32x2_t wv = lds_ld<lds_f32x2_t>(wm, ((dt * 3 + dy) * 3 + dx) * 96 * 4);
                     const float w0 = wv.x, w1 = wv.y;
 #pragma unroll
                     for (int x = 0; x < P::XO; ++x) {
@@ -809,8 +808,7 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int x = 0; x < 2 * P::XO; ++x) acc[py][x][0] = acc[py][x][1] = 0.f;
-        const float* wm = wm0;
-        asm volatile("" : "+v"(wm));             // keep the weight reads inside the loop
+        const lds_cptr_t wm = lds_opaque(wm0);    // keep the weight reads inside the loop, as LDS reads
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt) {
             const TA* tile = reinterpret_cast<const TA*>(dc_lds + ((t + 1 - dt + 3) % 3) * P::DC_BYTES) + 2 * cp;
@@ -825,7 +823,10 @@ __global__ __launch_bounds__(192, 2) void pool_dgrad2_tiled_kernel(const TA* __r
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) wv[dy][dx] = *reinterpret_cast<const float2*>(wm + ((dt * 3 + dy) * 3 + dx) * 96);
+                for (int dx = 0; dx < 3; ++dx) {
+                    const lds_f32x2_t t2 = lds_ld<lds_f32x2_t>(wm, ((dt * 3 + dy) * 3 + dx) * 96 * 4);
+                    wv[dy][dx] = make_float2(t2.x, t2.y);
+                }
 #pragma unroll
             for (int xo = 0; xo < P::XO; ++xo) {
                 // even input row y = 2*yo: dy = 1 -> d_conv row yo;  odd row y = 2*yo+1: dy = 0 -> row yo+1, dy = 2 -> row yo

@@ -228,8 +228,8 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
         if (P::NBUF == 2 && f + 1 < T) dma(f + 1, cur ^ 1);
         flush();                           // output frame f-2
         const char* tile = smem + cur * P::IN_BYTES + cp * 2 * ES;
-        const char* wm = reinterpret_cast<const char*>(wl) + cp * 8;
-        asm volatile("" : "+v"(wm));     // keep the 27 weight reads inside the loop (hoisted they would pin 54 registers)
+        // keep the 27 weight reads inside the loop (hoisted they would pin 54 registers) -- as LDS reads (see lds_opaque)
+        const lds_cptr_t wm = lds_opaque(reinterpret_cast<const char*>(wl) + cp * 8);
 #pragma unroll 1
         for (int dy = 0; dy < 3; ++dy) {
             f32x2 xin[P::IW];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
             for (int dt = 0; dt < 3; ++dt)      // input frame f is tap dt of output frame f + 1 - dt -> accumulator set 2 - dt
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const f32x2 wv = *reinterpret_cast<const f32x2*>(wm + ((dt * 3 + dy) * 3 + dx) * 384);
+                    const f32x2 wv = lds_ld<f32x2>(wm, ((dt * 3 + dy) * 3 + dx) * 384);
 #pragma unroll
                     for (int x = 0; x < P::XO; ++x) {      // plain v_fma_f32 x 2: v_pk_fma_f32 issues at well under half their rate on gfx950
                         acc[2 - dt][x].x = fmaf(wv.x, xin[S * x + dx].x, acc[2 - dt][x].x);
