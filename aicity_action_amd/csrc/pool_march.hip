@@ -24,6 +24,12 @@
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// timing ablations (tools/r5_march_abl.sh builds variant libraries; the product is always built with 0):
+//   1 no tap arithmetic   2 no LayerNorm (pack the raw conv)   4 no DMA after frame 0   8 no output stores   16 no per-frame barrier
+#ifndef MARCH_ABL
+#define MARCH_ABL 0
+#endif
+
 template <typename TA, int S>
 struct March {
     static constexpr int ROWS = 7, XO = 7;
@@ -38,26 +44,41 @@ struct March {
     static constexpr int SMEM = NBUF * IN_BYTES + W_BYTES;
 };
 
-// sums over the 64 lanes of a wave of N independent values, every lane gets every total.  Level by level over all N values:
-// the N butterflies interleave, so no DPP operand is read in the two wait states behind the VALU write that produced it (called
-// per value, every v_add_f32_dpp carried an s_nop 1).
+// Totals over the 64 lanes of a wave of N <= 8 independent per-lane values, TRANSPOSED: instead of one 6-level butterfly per value
+// (8 VALU each: 64 for 8 values) the values are folded into each other -- two registers become one whose lane halves carry the
+// half-sums of the two (v_permlane32_swap + add), two of those become one whose four 16-lane rows carry four values
+// (v_permlane16_swap + add), and only the within-row levels (4 DPP adds) run per register: 6 + 3 + 2 x 4 = 20 VALU for 8 values.
+// On return q[m] holds, in every lane of row r, the total of value 4m + ROW_TO_VAL[r] (ROW_TO_VAL = 0, 2, 1, 3): the caller
+// finishes its per-token arithmetic on the two registers (each lane = one token's scalar) and fetches scalars with
+// wave_sum_pick (v_readlane: a wave-uniform SGPR operand, no broadcast arithmetic).
 template <int N>
-__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+__device__ __forceinline__ void wave_sum_rows(const float (&v)[N], float (&q)[2]) {
+    static_assert(N <= 8, "at most 8 values");
+    float h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = 2 * k < N ? v[2 * k] : 0.f, b = 2 * k + 1 < N ? v[2 * k + 1] : 0.f;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        h[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // lanes 0-31: half-sums of a, lanes 32-63: of b
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[2 * m]), __float_as_uint(h[2 * m + 1]), false, false);
+        q[m] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // rows: v[4m], v[4m+2], v[4m+1], v[4m+3]
+    }
 #define DPP_LEVEL(CTRL)                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < N; ++i)                                                                 \
-        v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), CTRL, 0xF, 0xF, false));
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                 \
+        q[m] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q[m]), CTRL, 0xF, 0xF, false));
     DPP_LEVEL(0xB1)      // quad_perm [1,0,3,2]
     DPP_LEVEL(0x4E)      // quad_perm [2,3,0,1]
     DPP_LEVEL(0x141)     // row_half_mirror
     DPP_LEVEL(0x140)     // row_mirror
 #undef DPP_LEVEL
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i]), 0x401F));      // lane ^ 16
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-        v[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
+}
+// the scalar of value i from the row registers of wave_sum_rows (wave-uniform)
+__device__ __forceinline__ float wave_sum_pick(const float (&q)[2], int i) {
+    const int r = i & 3, row = r == 0 ? 0 : (r == 2 ? 1 : (r == 1 ? 2 : 3));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[i >> 2]), 16 * row));
 }
 
 template <typename TA>
@@ -163,42 +184,47 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
         if constexpr (sizeof(TA) == 2) return pack_bf16x2(a, b2_);
         else return make_float2(a, b2_);
     };
-    auto finalize = [&](int fo) {        // arithmetic only
+    auto finalize = [&](auto SET, int fo) {        // arithmetic only; SET = which accumulator set holds output frame fo
+        constexpr int a0 = decltype(SET)::value;
         pend_fo = fo;
         if (!row_ok) return;             // wave-uniform
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 || (MARCH_ABL & 2)) {
 #pragma unroll
-            for (int x = 0; x < P::XO; ++x) pend_o[x] = pack(acc[0][x].x, acc[0][x].y);
+            for (int x = 0; x < P::XO; ++x) pend_o[x] = pack(acc[a0][x].x, acc[a0][x].y);
         } else {
-            float mean[P::XO], rstd[P::XO];
+            float part[P::XO], q[2];
 #pragma unroll
-            for (int x = 0; x < P::XO; ++x) mean[x] = live ? acc[0][x].x + acc[0][x].y : 0.f;
-            wave_sum_n<P::XO>(mean);
+            for (int x = 0; x < P::XO; ++x) part[x] = live ? acc[a0][x].x + acc[a0][x].y : 0.f;
+            wave_sum_rows<P::XO>(part, q);
+            q[0] *= (1.0f / 96.0f);
+            q[1] *= (1.0f / 96.0f);
+            f32x2 d[P::XO];
 #pragma unroll
             for (int x = 0; x < P::XO; ++x) {
-                mean[x] *= (1.0f / 96.0f);
-                const float d0 = acc[0][x].x - mean[x], d1 = acc[0][x].y - mean[x];
-                acc[0][x].x = d0;
-                acc[0][x].y = d1;
-                rstd[x] = live ? d0 * d0 + d1 * d1 : 0.f;
+                const float mean = wave_sum_pick(q, x);
+                d[x].x = acc[a0][x].x - mean;
+                d[x].y = acc[a0][x].y - mean;
+                part[x] = live ? d[x].x * d[x].x + d[x].y * d[x].y : 0.f;
             }
-            wave_sum_n<P::XO>(rstd);
+            wave_sum_rows<P::XO>(part, q);
+            // v_rsq_f32 (1 ulp): one instruction, not the 25-instruction IEEE sqrt + divide -- and on the two row registers (every
+            // lane of a row = that row's token), not once per token
+            q[0] = __builtin_amdgcn_rsqf(q[0] * (1.0f / 96.0f) + eps);
+            q[1] = __builtin_amdgcn_rsqf(q[1] * (1.0f / 96.0f) + eps);
 #pragma unroll
             for (int x = 0; x < P::XO; ++x) {
-                rstd[x] = __builtin_amdgcn_rsqf(rstd[x] * (1.0f / 96.0f) + eps);       // v_rsq_f32 (1 ulp): one instruction, not the
-                const float h0 = acc[0][x].x * rstd[x], h1 = acc[0][x].y * rstd[x];     // 25-instruction IEEE sqrt + divide, per lane
-                if constexpr (MODE == 1) pend_h[x] = pack(h0, h1);
+                const float rstd = wave_sum_pick(q, x);
+                const float h0 = d[x].x * rstd, h1 = d[x].y * rstd;
+                if constexpr (MODE == 1) {
+                    pend_h[x] = pack(h0, h1);
+                    pend_r = (x == 0 || lane == x) ? rstd : pend_r;
+                }
                 pend_o[x] = pack(fmaf(h0, g2.x, b2.x), fmaf(h1, g2.y, b2.y));
-            }
-            if constexpr (MODE == 1) {
-                pend_r = rstd[0];
-#pragma unroll
-                for (int x = 1; x < P::XO; ++x) pend_r = lane == x ? rstd[x] : pend_r;
             }
         }
     };
     auto flush = [&]() {                 // stores of the pending frame
-        if (pend_fo < 0 || !row_ok) return;
+        if (pend_fo < 0 || !row_ok || (MARCH_ABL & 8)) return;
         const int fo = pend_fo;
         if constexpr (MODE == 2) {
             const int ob = bh / out_heads, og = bh - ob * out_heads;
@@ -221,47 +247,58 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
     };
 
     // ---- the march ---------------------------------------------------------------------------------------------------------
-    for (int f = 0; f < T; ++f) {
+    // Output frame fo lives in accumulator set fo % 3 for its whole life (the frame body is instantiated for the three phases
+    // f % 3, so the set indices are compile-time: no register copies rotate the sets -- 28 v_mov per frame before round 5).
+    auto frame = [&](auto PH, int f) {
+        constexpr int ph = decltype(PH)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // frame f has landed (this wave's pieces) ...
-        __builtin_amdgcn_s_barrier();                              // ... and everyone's; all waves are past frame f-1's reads
+        if (!(MARCH_ABL & 16)) __builtin_amdgcn_s_barrier();       // ... and everyone's; all waves are past frame f-1's reads
         const int cur = P::NBUF == 2 ? (f & 1) : 0;
-        if (P::NBUF == 2 && f + 1 < T) dma(f + 1, cur ^ 1);
+        if (P::NBUF == 2 && f + 1 < T && !(MARCH_ABL & 4)) dma(f + 1, cur ^ 1);
         flush();                           // output frame f-2
         const char* tile = smem + cur * P::IN_BYTES + cp * 2 * ES;
         // keep the 27 weight reads inside the loop (hoisted they would pin 54 registers) -- as LDS reads (see lds_opaque)
         const lds_cptr_t wm = lds_opaque(reinterpret_cast<const char*>(wl) + cp * 8);
 #pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {
+        for (int dy = 0; dy < ((MARCH_ABL & 1) ? 0 : 3); ++dy) {
             f32x2 xin[P::IW];
             const char* rp = tile + (S * row + dy) * P::IW * 96 * ES;
 #pragma unroll
             for (int ix = 0; ix < P::IW; ++ix) xin[ix] = lds_pair<TA>(rp + ix * 96 * ES);
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)      // input frame f is tap dt of output frame f + 1 - dt -> accumulator set 2 - dt
+            for (int dt = 0; dt < 3; ++dt) {    // input frame f is tap dt of output frame f + 1 - dt -> set (f + 1 - dt) % 3
+                const int a = (ph + 4 - dt) % 3;
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const f32x2 wv = lds_ld<f32x2>(wm, ((dt * 3 + dy) * 3 + dx) * 384);
 #pragma unroll
                     for (int x = 0; x < P::XO; ++x) {      // plain v_fma_f32 x 2: v_pk_fma_f32 issues at well under half their rate on gfx950
-                        acc[2 - dt][x].x = fmaf(wv.x, xin[S * x + dx].x, acc[2 - dt][x].x);
-                        acc[2 - dt][x].y = fmaf(wv.y, xin[S * x + dx].y, acc[2 - dt][x].y);
+                        acc[a][x].x = fmaf(wv.x, xin[S * x + dx].x, acc[a][x].x);
+                        acc[a][x].y = fmaf(wv.y, xin[S * x + dx].y, acc[a][x].y);
                     }
                 }
+            }
         }
         if (P::NBUF == 1 && f + 1 < T) {   // single buffer: the next frame may only be requested once every wave has read this one
             __builtin_amdgcn_s_barrier();
             dma(f + 1, 0);
         }
-        if (f >= 1) finalize(f - 1);       // set 0 = output frame f-1 is complete
+        constexpr int done = (ph + 2) % 3;  // output frame f-1 is complete; its set then restarts as output frame f+2
+        if (f >= 1) finalize(std::integral_constant<int, done>{}, f - 1);
 #pragma unroll
-        for (int x = 0; x < P::XO; ++x) {
-            acc[0][x] = acc[1][x];
-            acc[1][x] = acc[2][x];
-            acc[2][x] = f32x2{0.f, 0.f};
-        }
+        for (int x = 0; x < P::XO; ++x) acc[done][x] = f32x2{0.f, 0.f};
+    };
+    for (int f0 = 0; f0 < T; f0 += 3) {
+        frame(std::integral_constant<int, 0>{}, f0);
+        if (f0 + 1 < T) frame(std::integral_constant<int, 1>{}, f0 + 1);
+        if (f0 + 2 < T) frame(std::integral_constant<int, 2>{}, f0 + 2);
     }
     flush();                               // output frame T-2
-    finalize(T - 1);
+    switch ((T - 1) % 3) {
+        case 0: finalize(std::integral_constant<int, 0>{}, T - 1); break;
+        case 1: finalize(std::integral_constant<int, 1>{}, T - 1); break;
+        default: finalize(std::integral_constant<int, 2>{}, T - 1); break;
+    }
     flush();
 }
 
