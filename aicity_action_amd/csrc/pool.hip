@@ -974,7 +974,8 @@ int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, c
 
 int mvit_internal_pool_march_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const float* beta, void* out,
                                  void* xhat, float* rstd, int B, int heads, int T, int H, int W, int stride_hw, float eps, int act_dtype,
-                                 hipStream_t st);      // pool_march.hip
+                                 hipStream_t st, const float* w2 = nullptr, const float* gamma2 = nullptr,
+                                 const float* beta2 = nullptr);      // pool_march.hip
 int mvit_internal_pool_march_dgrad1(const void* dconv, const float* w, void* dqkv, int64_t ld, int chan_off, int B, int heads, int T,
                                     int H, int W, int act_dtype, hipStream_t st);
 
@@ -994,11 +995,13 @@ extern "C" int mvit_pool_conv_ln_fwd_train(const void* qkv, int64_t ld, int chan
     if (act_dtype != MVIT_F32 && act_dtype != MVIT_BF16) return MVIT_EDTYPE;
     if ((int64_t)B * heads > 65535) return MVIT_EINVAL;
     if (stride_hw == 1 || stride_hw == 2) {
-        // pool_march.hip (7 x 7 tiles, in-register LayerNorm) where it measured faster than the 8-wide tiles below: stride 1 on
-        // the <= 56 x 56 grids (56: 93 vs 99 us, 14: 31 vs 34 us, 28: tie; 112 x 112 and stride 2: 8-wide tiles 5-15 % faster --
-        // both forms are fp32-VALU-bound).  MVIT_POOL_MARCH=0 / 1 forces one form (A/B).
+        // pool_march.hip (7 x 7 tiles, in-register LayerNorm).  Rounds 2-4 used it for stride 1 on the <= 56 x 56 grids only; since the
+        // round-5 work on it (LDS weight reads, static accumulator sets, transposed LayerNorm reduction) it is ahead of the 8-wide tiles
+        // below on every shape of the model (profiles/r5_pool_*.txt): stride 2 at 28 / 56 / 112: 25.6 / 28.5 / 60.8 against 29.1 / 36.0 /
+        // 70.1 us.  MVIT_POOL_MARCH=0 / 1 forces one form (A/B); MVIT_POOL_MARCH_MAXW bounds the grids it takes at stride 1.
         static const int march_env = getenv("MVIT_POOL_MARCH") ? atoi(getenv("MVIT_POOL_MARCH")) : -1;
-        const bool march = march_env >= 0 ? march_env != 0 : (stride_hw == 1 && W <= 56);
+        static const int march_maxw = getenv("MVIT_POOL_MARCH_MAXW") ? atoi(getenv("MVIT_POOL_MARCH_MAXW")) : (1 << 30);    // (112 x 112: 158 vs 172 us)
+        const bool march = march_env >= 0 ? march_env != 0 : (stride_hw == 2 || W <= march_maxw);
         if (march) {
             const int rc = mvit_internal_pool_march_fwd(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, stride_hw, eps,
                                                         act_dtype, st);
@@ -1039,6 +1042,12 @@ extern "C" int mvit_pool_conv_ln_fwd_train_kv(const void* qkv, int64_t ld, int c
     if (stride_hw != 2 || (int64_t)2 * B * heads > 65535) return MVIT_EUNSUPPORTED;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     hipStream_t st = as_stream(stream);
+    static const int march_env = getenv("MVIT_POOL_MARCH") ? atoi(getenv("MVIT_POOL_MARCH")) : -1;
+    if (march_env != 0) {       // the pair form of the march kernel (pool_march.hip): 2 x B x heads x tiles workgroups in one launch
+        const int rc = mvit_internal_pool_march_fwd(qkv, ld, chan_off_k, w_k, gamma_k, beta_k, out_kv, xhat_kv, rstd_kv, B, heads, T, H, W, 2, eps,
+                                                    act_dtype, st, w_v, gamma_v, beta_v);
+        if (rc != MVIT_EUNSUPPORTED) return rc;
+    }
     if (act_dtype == MVIT_BF16)
         return launch_pool_tiled<bf16_t, 2>(qkv, ld, chan_off_k, w_k, gamma_k, beta_k, out_kv, xhat_kv, rstd_kv, B, heads, T, H, W, Ho, Wo, eps, st,
                                             w_v, gamma_v, beta_v);

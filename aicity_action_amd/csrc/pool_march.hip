@@ -108,7 +108,10 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
                                                          const float* __restrict__ beta, TA* __restrict__ out,
                                                          TA* __restrict__ xhat, float* __restrict__ rstd_out, int heads, int T,
                                                          int H, int W, int Ho, int Wo, float eps, int64_t out_ld,
-                                                         int out_chan_off, int out_heads) {
+                                                         int out_chan_off, int out_heads, int set_bh, const float* __restrict__ w2,
+                                                         const float* __restrict__ gamma2, const float* __restrict__ beta2) {
+    // set_bh > 0: TWO tensors in one launch (the k and the v pooling conv of a block: adjacent head groups of the fused qkv buffer,
+    // own conv weights / LayerNorm parameters, outputs back to back): blockIdx.y = set * set_bh + (b * heads + g)
     using P = March<TA, S>;
     constexpr int ES = (int)sizeof(TA);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,9 +123,11 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
     const int tiles_x = (Wo + P::XO - 1) / P::XO;
     const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
     const int bh = blockIdx.y;
-    const int b = bh / heads, g = bh - b * heads;
+    int bhs = bh, hoff = 0;
+    if (set_bh > 0 && bh >= set_bh) { bhs = bh - set_bh; hoff = heads; w = w2; gamma = gamma2; beta = beta2; }
+    const int b = bhs / heads, g = bhs - b * heads;
     const int64_t Nin = (int64_t)T * H * W;
-    const char* base = reinterpret_cast<const char*>(in + (int64_t)b * Nin * ld + chan_off + g * 96);
+    const char* base = reinterpret_cast<const char*>(in + (int64_t)b * Nin * ld + chan_off + (hoff + g) * 96);
     const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
 
     // ---- one-time setup: weights, zeroed tiles, per-thread DMA offsets ------------------------------------------------------
@@ -305,9 +310,10 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
 template <typename TA, int S, int MODE>
 static int launch_march(const void* in, int64_t ld, int chan_off, const float* w, const float* gamma, const float* beta, void* out,
                         void* xhat, float* rstd, int B, int heads, int T, int H, int W, int Ho, int Wo, float eps, int64_t out_ld,
-                        int out_chan_off, int out_heads, hipStream_t st) {
+                        int out_chan_off, int out_heads, hipStream_t st, const float* w2 = nullptr, const float* gamma2 = nullptr,
+                        const float* beta2 = nullptr) {
     using P = March<TA, S>;
-    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads);
+    dim3 grid(((Wo + P::XO - 1) / P::XO) * ((Ho + P::ROWS - 1) / P::ROWS), B * heads * (w2 ? 2 : 1));
     static DevFlags attr_done_tab; DevFlag attr_done = dev_flag(attr_done_tab);
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_march_kernel<TA, S, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -316,7 +322,7 @@ static int launch_march(const void* in, int64_t ld, int chan_off, const float* w
         attr_done = true;
     }
     hipLaunchKernelGGL((pool_march_kernel<TA, S, MODE>), grid, dim3(P::NT), P::SMEM, st, (const TA*)in, ld, chan_off, w, gamma, beta,
-                       (TA*)out, (TA*)xhat, rstd, heads, T, H, W, Ho, Wo, eps, out_ld, out_chan_off, out_heads);
+                       (TA*)out, (TA*)xhat, rstd, heads, T, H, W, Ho, Wo, eps, out_ld, out_chan_off, out_heads, w2 ? B * heads : 0, w2, gamma2, beta2);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -324,13 +330,14 @@ static int launch_march(const void* in, int64_t ld, int chan_off, const float* w
 // internal entry points (pool.hip / pool_bwd.hip): forward (+ saved statistics) for strides 1 and 2 ...
 int mvit_internal_pool_march_fwd(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const float* beta, void* out,
                                  void* xhat, float* rstd, int B, int heads, int T, int H, int W, int stride_hw, float eps, int act_dtype,
-                                 hipStream_t st) {
+                                 hipStream_t st, const float* w2, const float* gamma2, const float* beta2) {
+    // (w2 / gamma2 / beta2 non-null: the pair form -- a second tensor's head group follows the first's in the input, see the kernel)
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
     // frame / tile offsets are 32-bit byte offsets from a per-(batch, head) 64-bit base
     if ((int64_t)H * W * ld * 4 >= (1ll << 31)) return MVIT_EUNSUPPORTED;
 #define MARCH(TA, S)                                                                                                                   \
-    (xhat ? launch_march<TA, S, 1>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, 0, 0, 1, st)    \
-          : launch_march<TA, S, 0>(qkv, ld, chan_off, w, gamma, beta, out, nullptr, nullptr, B, heads, T, H, W, Ho, Wo, eps, 0, 0, 1, st))
+    (xhat ? launch_march<TA, S, 1>(qkv, ld, chan_off, w, gamma, beta, out, xhat, rstd, B, heads, T, H, W, Ho, Wo, eps, 0, 0, 1, st, w2, gamma2, beta2)    \
+          : launch_march<TA, S, 0>(qkv, ld, chan_off, w, gamma, beta, out, nullptr, nullptr, B, heads, T, H, W, Ho, Wo, eps, 0, 0, 1, st, w2, gamma2, beta2))
     if (act_dtype == MVIT_BF16) return stride_hw == 1 ? MARCH(bf16_t, 1) : MARCH(bf16_t, 2);
     return stride_hw == 1 ? MARCH(float, 1) : MARCH(float, 2);
 #undef MARCH
