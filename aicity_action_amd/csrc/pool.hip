@@ -936,15 +936,31 @@ int mvit_internal_pool_dgrad2_tiled_kv(const void* dconv_kv, const float* w_k, c
     return act_dtype == MVIT_BF16 ? launch_pool_dgrad2_tiled<bf16_t>(dconv_kv, w_k, dqkv, ld, chan_off_k, B, heads, T, H, W, Ho, Wo, st, w_v)
                                   : launch_pool_dgrad2_tiled<float>(dconv_kv, w_k, dqkv, ld, chan_off_k, B, heads, T, H, W, Ho, Wo, st, w_v);
 }
+// pool_march.hip: the march form of the weight gradient (16-bit builds: v_dot2c over token pairs, 7 x 7 tiles); MVIT_POOL_WGRAD_MARCH=0
+// keeps the 8-wide tiles below (A/B)
+int mvit_internal_pool_wgrad_march(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads, int T, int H,
+                                   int W, int stride_hw, int nset, hipStream_t st);
+static bool wgrad_march_on() {
+    static const bool on = !(getenv("MVIT_POOL_WGRAD_MARCH") && getenv("MVIT_POOL_WGRAD_MARCH")[0] == '0');
+    return on;
+}
 int mvit_internal_pool_wgrad_tiled_kv(const void* qkv, int64_t ld, int chan_off_k, const void* dconv_kv, float* part, int B, int heads,
                                       int T, int H, int W, int act_dtype, hipStream_t st) {       // returns the partial rows of BOTH sets
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (act_dtype == MVIT_BF16 && wgrad_march_on()) {
+        const int rc = mvit_internal_pool_wgrad_march(qkv, ld, chan_off_k, dconv_kv, part, B, heads, T, H, W, 2, 2, st);
+        if (rc != MVIT_EUNSUPPORTED) return rc;
+    }
     return act_dtype == MVIT_BF16 ? launch_pool_wgrad_tiled<bf16_t, 2>(qkv, ld, chan_off_k, dconv_kv, part, B, heads, T, H, W, Ho, Wo, st, 2)
                                   : launch_pool_wgrad_tiled<float, 2>(qkv, ld, chan_off_k, dconv_kv, part, B, heads, T, H, W, Ho, Wo, st, 2);
 }
 int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads,
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st) {
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    if (act_dtype == MVIT_BF16 && wgrad_march_on()) {
+        const int rc = mvit_internal_pool_wgrad_march(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, stride_hw, 1, st);
+        if (rc != MVIT_EUNSUPPORTED) return rc;
+    }
     if (stride_hw == 1)
         return act_dtype == MVIT_BF16 ? launch_pool_wgrad_tiled<bf16_t, 1>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st)
                                       : launch_pool_wgrad_tiled<float, 1>(qkv, ld, chan_off, dconv, part, B, heads, T, H, W, Ho, Wo, st);

@@ -338,7 +338,11 @@ extern "C" int64_t mvit_pool_bwd_workspace_bytes(int B, int heads, int T, int H,
     if (stride_hw == 2) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
     if (rows < PB_MAXBLK) rows = PB_MAXBLK;
     (void)T;
-    const int64_t wrows = rows > PW_MAXBLK ? rows : PW_MAXBLK;    // tiled wgrad: one [2592] partial row per tile workgroup
+    int64_t wrows = rows > PW_MAXBLK ? rows : PW_MAXBLK;    // tiled wgrad: one [2592] partial row per tile workgroup
+    if (stride_hw == 1 || stride_hw == 2) {                 // ... of the 8-wide tiles or of the 7 x 7 tiles of the march form, whichever is more
+        const int64_t mrows = (int64_t)((Wo + 6) / 7) * ((Ho + 6) / 7) * B * heads;
+        if (mrows > wrows) wrows = mrows;
+    }
     return (rows * 192 + wrows * 2592) * (int64_t)sizeof(float);
 }
 

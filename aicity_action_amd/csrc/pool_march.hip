@@ -353,3 +353,218 @@ int mvit_internal_pool_march_dgrad1(const void* dconv, const float* w, void* dqk
     return launch_march<float, 1, 2>(dconv, 96, 0, w, nullptr, nullptr, dqkv, nullptr, nullptr, B * heads, 1, T, H, W, H, W, 0.f, ld,
                                      chan_off, heads, st);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the pooling conv in the march form (round 5; 16-bit builds, strides 1 and 2):
+//   dw[c][dt][dy][dx] = sum_tokens d_conv[(to, yo, xo)][c] * in[(to + dt - 1, S yo + dy - 1, S xo + dx - 1)][c]      (attention.py:56 backward)
+// Same skeleton as the forward (7 waves = the 7 rows of a 7 x 7 d_conv tile, lane = channel pair, input halo frames by LDS-DMA,
+// double-buffered).  What is different:
+//   * the sum over a row's 7 tokens is a DOT PRODUCT of two 16-bit activation vectors, so it runs on v_dot2c_f32_{bf16,f16}
+//     (two multiply-adds per instruction, fp32 accumulation, operands used as they are stored -- no unpacking and, unlike in the
+//     forward, no weight to round): the channel-pair registers of two neighbouring tokens are turned into token-pair registers of
+//     one channel by v_perm_b32, a row's 7 tokens become 4 pairs (the last one padded with a zero), and a tap costs 4 dot2
+//     instead of 7 fma: 216 + 62 permutes per frame against 378 + 68 unpack operations in the 8-wide form of pool.hip;
+//   * a lane needs d_conv only for its own row and channel pair: plain global loads into registers, one frame ahead, kept as a
+//     3-frame ring of token-pair registers whose slot names are compile-time (3-phase frame body) -- no LDS, no barrier for them;
+//   * the 27 x 2 sums of a lane live in registers over all frames; at the end the 7 rows are added IN ROW ORDER through one
+//     [tap][96] LDS slab (fixed summation order: bit-reproducible), one partial row [96 * 27] per workgroup for pool_reduce.
+// 7 x 7 tiles cover every token grid of the model exactly (the 8-wide tiles of pool.hip waste 23 % at 28 x 28 and 14 x 14).
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot2_16(uint32_t a, uint32_t b, float c) {
+#ifdef MVIT_HALF_IS_FP16
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+#endif
+}
+// (lo16 of a, lo16 of b) and (hi16 of a, hi16 of b): the two channels of a lane's pair, each as a two-token vector
+__device__ __forceinline__ uint32_t pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+template <int S>
+__global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __restrict__ in, int64_t ld, int chan_off,
+                                                               const bf16_t* __restrict__ dconv, float* __restrict__ part, int heads,
+                                                               int T, int H, int W, int Ho, int Wo, int set_bh) {
+    using P = March<bf16_t, S>;
+    constexpr int ES = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int row = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool live = lane < 48;
+    const int cp = live ? lane : 47;
+    const int tiles_x = (Wo + P::XO - 1) / P::XO;
+    const int tx0 = (blockIdx.x % tiles_x) * P::XO, ty0 = (blockIdx.x / tiles_x) * P::ROWS;
+    const int bh = blockIdx.y;
+    const int hoff = (set_bh > 0 && bh >= set_bh) ? heads : 0, bhs = hoff ? bh - set_bh : bh;
+    const int b = bhs / heads, g = bhs - b * heads;
+    const int64_t Nin = (int64_t)T * H * W;
+    const char* base = reinterpret_cast<const char*>(in + (int64_t)b * Nin * ld + chan_off + (hoff + g) * 96);
+    const int y_in0 = S * ty0 - 1, x_in0 = S * tx0 - 1;
+
+    for (int i = tid; i < P::NBUF * P::IN_BYTES / 16; i += P::NT) *reinterpret_cast<uint4*>(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    uint32_t poff[P::PF];
+#pragma unroll
+    for (int i = 0; i < P::PF; ++i) {
+        const int c = tid + P::NT * i;
+        poff[i] = 0xffffffffu;
+        if (c < P::NCHUNK) {
+            const int tok = c / P::CPT, ch = c - tok * P::CPT;
+            const int iy = tok / P::IW, ix = tok - iy * P::IW;
+            const int y = y_in0 + iy, x = x_in0 + ix;
+            if (y >= 0 && y < H && x >= 0 && x < W) poff[i] = (uint32_t)(((int64_t)(y * W + x) * ld) * ES + ch * 16);
+        }
+    }
+    const int64_t frame_bytes = (int64_t)H * W * ld * ES;
+    const uint32_t smem_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma = [&](int f, int buf) {
+        const char* fb = base + f * frame_bytes;
+#pragma unroll
+        for (int i = 0; i < P::PF; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_a + buf * P::IN_BYTES + 1024 * (row + P::ROWS * i));
+            if (poff[i] != 0xffffffffu)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(poff[i]), "s"(fb) : "memory");
+        }
+    };
+    __syncthreads();
+    dma(0, 0);
+
+    // d_conv of this lane: row yo, tokens tx0 .. tx0+6, channel pair cp of output frame fo -> 7 dwords (zero outside the grid / for the
+    // 16 idle lanes, whose sums therefore stay zero)
+    const int yo = ty0 + row;
+    const bool row_ok = yo < Ho;
+    const uint32_t* drow = reinterpret_cast<const uint32_t*>(dconv + ((int64_t)bh * T * Ho * Wo + (int64_t)(row_ok ? yo : 0) * Wo + tx0) * 96) + cp;
+    const int64_t dframe = (int64_t)Ho * Wo * 48;      // dwords per output frame
+    uint32_t raw[P::XO];
+    auto load_d = [&](int fo) {
+        const uint32_t* p = drow + fo * dframe;
+#pragma unroll
+        for (int x = 0; x < P::XO; ++x) raw[x] = (tx0 + x < Wo) ? p[x * 48] : 0u;      // (clamped-address form: the test only picks the value)
+    };
+    uint32_t pd[3][4][2];       // [output frame % 3][token pair][channel of the lane's pair]
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pd[s][k][0] = pd[s][k][1] = 0u;
+    const uint32_t keep = (live && row_ok) ? 0xffffffffu : 0u;
+    auto convert = [&](auto SLOT, bool ok) {       // raw -> token-pair registers of slot SLOT (zeros for a frame outside [0, T))
+        constexpr int s = decltype(SLOT)::value;
+        const uint32_t m = ok ? keep : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pd[s][k][0] = pair_lo(raw[2 * k], raw[2 * k + 1]) & m;
+            pd[s][k][1] = pair_hi(raw[2 * k], raw[2 * k + 1]) & m;
+        }
+        pd[s][3][0] = (raw[6] & 0xffffu) & m;
+        pd[s][3][1] = (raw[6] >> 16) & m;
+    };
+    load_d(0);
+    convert(std::integral_constant<int, 0>{}, true);
+    if (T > 1) load_d(1);
+
+    float acc[27][2];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t][0] = acc[t][1] = 0.f;
+
+    auto frame = [&](auto PH, int f) {
+        constexpr int ph = decltype(PH)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // input frame f (this wave's pieces) and the d_conv registers of frame f+1
+        __builtin_amdgcn_s_barrier();
+        const int cur = P::NBUF == 2 ? (f & 1) : 0;
+        convert(std::integral_constant<int, (ph + 1) % 3>{}, f + 1 < T);     // d_conv frame f+1 (tap dt = 0) replaces frame f-2
+        if (P::NBUF == 2 && f + 1 < T) dma(f + 1, cur ^ 1);
+        if (f + 2 < T) load_d(f + 2);
+        const char* tile = smem + cur * P::IN_BYTES + cp * 2 * ES;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            uint32_t xr[P::IW];
+            const char* rp = tile + (S * row + dy) * P::IW * 96 * ES;
+#pragma unroll
+            for (int ix = 0; ix < P::IW; ++ix) xr[ix] = *reinterpret_cast<const uint32_t*>(rp + ix * 96 * ES);
+            // token pairs of the input row: output tokens (2k, 2k+1) meet inputs (S 2k + dx, S (2k+1) + dx); the 7th token alone
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                uint32_t pi[4][2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pi[k][0] = pair_lo(xr[S * 2 * k + dx], xr[S * (2 * k + 1) + dx]);
+                    pi[k][1] = pair_hi(xr[S * 2 * k + dx], xr[S * (2 * k + 1) + dx]);
+                }
+                pi[3][0] = xr[S * 6 + dx] & 0xffffu;
+                pi[3][1] = xr[S * 6 + dx] >> 16;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {       // input frame f is tap dt of output frame f + 1 - dt
+                    const int s = (ph + 4 - dt) % 3, tap = (dt * 3 + dy) * 3 + dx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[tap][0] = dot2_16(pd[s][k][0], pi[k][0], acc[tap][0]);
+                        acc[tap][1] = dot2_16(pd[s][k][1], pi[k][1], acc[tap][1]);
+                    }
+                }
+            }
+        }
+        if (P::NBUF == 1 && f + 1 < T) {
+            __builtin_amdgcn_s_barrier();
+            dma(f + 1, 0);
+        }
+    };
+    for (int f0 = 0; f0 < T; f0 += 3) {
+        frame(std::integral_constant<int, 0>{}, f0);
+        if (f0 + 1 < T) frame(std::integral_constant<int, 1>{}, f0 + 1);
+        if (f0 + 2 < T) frame(std::integral_constant<int, 2>{}, f0 + 2);
+    }
+    // rows added in row order through one [tap][96] slab (aliases the input tiles: every wave is past its last tile read after the barrier)
+    float* red = reinterpret_cast<float*>(smem);
+    static_assert(27 * 96 * 4 <= P::IN_BYTES, "slab must fit the tile storage");
+    for (int r = 0; r < P::ROWS; ++r) {
+        __builtin_amdgcn_s_barrier();
+        if (row == r && live) {
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                float2* p = reinterpret_cast<float2*>(&red[t * 96 + 2 * cp]);
+                float2 v = make_float2(acc[t][0], acc[t][1]);
+                if (r > 0) { const float2 o = *p; v.x += o.x; v.y += o.y; }
+                *p = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    float* prow = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2592;
+    for (int i = tid; i < 2592; i += P::NT) {
+        const int c = i / 27, t = i - c * 27;          // output index c * 27 + tap (the layout pool_reduce and the conv weight share)
+        prow[i] = red[t * 96 + c];
+    }
+}
+
+// weight-gradient partial rows, march form: returns the number of rows written ([2592] each), MVIT_EUNSUPPORTED for shapes it does not take
+int mvit_internal_pool_wgrad_march(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads, int T, int H,
+                                   int W, int stride_hw, int nset, hipStream_t st) {
+    if (stride_hw != 1 && stride_hw != 2) return MVIT_EUNSUPPORTED;
+    if ((int64_t)H * W * ld * 2 >= (1ll << 31)) return MVIT_EUNSUPPORTED;
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    dim3 grid(((Wo + 6) / 7) * ((Ho + 6) / 7), nset * B * heads);
+#define WG_LAUNCH(S)                                                                                                                      \
+    {                                                                                                                                     \
+        using P = March<bf16_t, S>;                                                                                                       \
+        constexpr int SM = P::NBUF * P::IN_BYTES;                                                                                         \
+        static DevFlags attr_tab; DevFlag attr_done = dev_flag(attr_tab);                                                                 \
+        if (!attr_done) {                                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_march_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess) \
+                return MVIT_ELAUNCH;                                                                                                      \
+            attr_done = true;                                                                                                             \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((pool_wgrad_march_kernel<S>), grid, dim3(P::NT), SM, st, (const bf16_t*)qkv, ld, chan_off, (const bf16_t*)dconv, \
+                           part, heads, T, H, W, Ho, Wo, nset == 2 ? B * heads : 0);                                                      \
+    }
+    if (stride_hw == 1) WG_LAUNCH(1) else WG_LAUNCH(2)
+#undef WG_LAUNCH
+    MVIT_LAUNCH_CHECK();
+    return (int)(grid.x * grid.y);
+}
+// rows mvit_internal_pool_wgrad_march writes for one tensor (workspace sizing)
+int64_t mvit_internal_pool_wgrad_march_rows(int B, int heads, int H, int W, int stride_hw) {
+    const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
+    return (int64_t)((Wo + 6) / 7) * ((Ho + 6) / 7) * B * heads;
+}

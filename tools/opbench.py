@@ -238,6 +238,30 @@ def main():
         ntok = B * h * T * Ho * Wo
         print("pool B=%d h=%d THW=%dx%dx%d s=%d: %.1f us  %.2f Gtok/s  %.2f TB/s(out+in slice)" % (
             B, h, T, H, W, s, ms * 1e3, ntok / ms / 1e6, (ntok * 192 + B * h * T * H * W * 192) / ms / 1e9))
+    elif op == "poolbwd":       # backward of one pooling conv + LayerNorm from saved statistics: B h T H W stride [reps]; MVIT_POOL_WGRAD_MARCH=0/1 A/B
+        B, h, T, H, W, s = (int(v) for v in a[:6])
+        reps = int(a[6]) if len(a) > 6 else 20
+        C = 96 * h
+        qkv = torch.randn(B, T * H * W, 3 * C, device=dev).bfloat16()
+        w = torch.randn(96, 27, device=dev) * 0.2
+        g = torch.ones(96, device=dev)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        ntok = B * h * T * Ho * Wo
+        xh = torch.randn(B, h, T * Ho * Wo, 96, device=dev).bfloat16()
+        rs = torch.rand(ntok, device=dev) + 0.5
+        dout = torch.randn_like(xh)
+        dconv = torch.empty_like(xh)
+        dqkv = torch.zeros_like(qkv)
+        dw, dg, db = torch.zeros(96, 27, device=dev), torch.zeros(96, device=dev), torch.zeros(96, device=dev)
+        nb = L.mvit_pool_bwd_workspace_bytes(B, h, T, H, W, s)
+        ws = torch.empty(nb // 4, device=dev)
+
+        def fn():
+            _hip.check(L.mvit_pool_conv_ln_bwd_saved(_hip.ptr(qkv), 3 * C, 0, _hip.ptr(w), _hip.ptr(g), _hip.ptr(xh), _hip.ptr(rs), _hip.ptr(dout),
+                                                     _hip.ptr(dconv), _hip.ptr(dqkv), _hip.ptr(dw), _hip.ptr(dg), _hip.ptr(db), 1, _hip.ptr(ws),
+                                                     B, h, T, H, W, s, 1e-5, _hip.BF16, st))
+        ms = timeit(fn, reps)
+        print("pool backward (LN bwd + wgrad + reduces + dgrad) B=%d h=%d THW=%dx%dx%d s=%d: %.1f us" % (B, h, T, H, W, s, ms * 1e3))
     elif op == "poolkv":
         B, h, T, H, W = (int(v) for v in a[:5])
         reps = int(a[5]) if len(a) > 5 else 20
