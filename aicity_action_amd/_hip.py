@@ -34,11 +34,9 @@ _SIGS = {
     "mvit_mlp_fused_fwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_p]),
     "mvit_block_tail_pack_bytes": (c_l, [c_i, c_i]),
     "mvit_block_tail_pack": (c_i, [c_p] * 8 + [c_i, c_i, c_p]),
-    "mvit_block_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),
+    "mvit_block_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_attention_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
-    "mvit_attention_fwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i, c_i]),
-    "mvit_attention_fwd_ws": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_l, c_p]),
     "mvit_maxpool_skip_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "mvit_stem_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "mvit_head_workspace_bytes": (c_l, [c_i, c_i, c_i]),
@@ -68,7 +66,6 @@ _SIGS = {
     "mvit_colsum": (c_i, [c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_i, c_p, c_p]),
     "mvit_attention_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i]),
     "mvit_attention_bwd": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
-    "mvit_attention_bwd_dq_w64": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_bwd_workspace_bytes": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "mvit_pool_conv_ln_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "mvit_pool_conv_ln_fwd_train": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
@@ -136,25 +133,11 @@ def lib(half="bf16"):
     return _lib
 
 
-# MVIT_ATT_TAIL_SPLIT=1: the ragged last query tile of every (batch, head) runs key-split (mvit_attention_fwd_ws).  Built, parity-tested
-# and measured in round 4 (profiles/r4_attn_tail.txt): stage-3 forward 168.2 -> 158.9 us of kernel time at B = 8 (768 workgroups = 3
-# whole rounds of the chip), but 77.5 -> 96 us for the 3-clip sub-batches the inference path launches (no round is saved there, the
-# split's fixed cost is added) and 82 -> 114 us at Lq = 1568 -- and the choice may not depend on the batch (rows must not change with
-# the batch they are in).  Off by default.
-_ATT_TAIL = os.environ.get("MVIT_ATT_TAIL_SPLIT", "0") == "1"
-
-
 def attention_fwd(L, q, k, v, o, lse, B, h, Lq, Lk, scale, add_q, act, st):
-    """mvit_attention_fwd, or (MVIT_ATT_TAIL_SPLIT=1) mvit_attention_fwd_ws with its workspace (key-split ragged query tile,
-    include/mvit_hip.h); the workspace is an ordinary stream-ordered torch allocation.  A batch-dependent choice (split only where a launch
-    fills whole rounds) was tried for the training forward: the train step moved by 0.1 ms (162.8 -> 163.1 clips/s, noise) and the
-    per-clip logits stopped being batch-independent (tests/test_hip_train.py::test_bench_size_bf16_train_step_properties): not kept."""
-    nb = L.mvit_attention_fwd_workspace_bytes(B, h, Lq, Lk, act) if _ATT_TAIL else 0
-    if nb <= 0:
-        return L.mvit_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, st)
-    import torch
-    ws = torch.empty(nb // 4, dtype=torch.float32, device=q.device)
-    return L.mvit_attention_fwd_ws(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, ptr(ws), nb, st)
+    """mvit_attention_fwd on torch tensors.  (A key-split form of the ragged last query tile was measured in round 4 -- stage-3 forward
+    168.2 -> 158.9 us at B = 8 but 77.5 -> 96 us for the 3-clip sub-batches of the inference path, and the choice may not depend on the
+    batch -- and left the library in round 5: tools/probes/attn_fwd_keysplit.patch, profiles/r4_attn_tail.txt.)"""
+    return L.mvit_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, st)
 
 
 def check(rc, what=""):

@@ -148,10 +148,6 @@ __global__ __launch_bounds__(192) void attn_bwd_delta_flat_kernel(const bf16_t* 
 // global_load_lds_dwordx4 with the rotation swizzle on the source address (two tiles in flight, one s_barrier per tile).
 // The K image serves both the row reads (S^T = K Q^T) and the transposing reads (dQ^T += K^T dS^T): the latter apply the
 // row's rotation to their own address and are issued as inline asm (no compiler vmcnt(0) in front of them).
-// attention_bwd_w64.hip
-int attn_bwd_dq_w64_prepare();
-int attn_bwd_dq_w64_launch(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta, void* dq, int B,
-                           int heads, int Lq, int Lk, float scale, float scale_log2e, int add_q, hipStream_t st);
 
 typedef __attribute__((address_space(1))) const void b_gptr_t;
 typedef __attribute__((address_space(3))) void b_lptr_t;
@@ -809,18 +805,6 @@ extern "C" int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, 
     return ws_qs_offset_floats(B, heads, Lq, Lk) * (int64_t)sizeof(float) + (int64_t)B * heads * Lq * 96 * 2;
 }
 
-// the 64-query form of pass A by itself (tests, tools): delta = mvit_attention_bwd's workspace head (fp32 [B*heads*Lq])
-extern "C" int mvit_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse, const float* delta,
-                                                  void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q, void* stream) {
-    if (!q || !k || !v || !dout || !lse || !delta || !dq || Lk < 64 || Lq < 1) return MVIT_EINVAL;
-    static DevFlags done_tab; DevFlag done = dev_flag(done_tab);
-    if (!done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; done = true; }
-    const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, delta, dq, B, heads, Lq, Lk, scale, scale * 1.44269504088896340736f, add_q, as_stream(stream));
-    if (rc != MVIT_OK) return rc;
-    MVIT_LAUNCH_CHECK();
-    return MVIT_OK;
-}
-
 // q,k,v as in the forward; out = forward output [B][Lq][heads*96]; lse from the forward; dout same layout as out.
 // dq [B][heads][Lq][96], dk/dv [B][heads][Lk][96] (act-typed).  workspace: fp32 [B*heads*Lq] (delta).
 extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
@@ -864,17 +848,8 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         const bool want_side = side_env ? side_env[0] == '1' : Lk > 2048;
         SideStream* ss = want_side ? side_stream_for_current_device() : nullptr;
         hipStream_t skv = (ss && side_fork(ss, st)) ? ss->side : st;
-        // pass A in the 64-queries-per-wave form (attention_bwd_w64.hip) only on request (MVIT_ATT_DQ_W64=1): it measured 4-12 % behind
-        // the 32-query kernel below (profiles/r3_attn_dq_w64.txt)
-        static const bool dq_w64_env = getenv("MVIT_ATT_DQ_W64") && atoi(getenv("MVIT_ATT_DQ_W64")) != 0;
-        const bool dq_w64 = dq_w64_env && attn_fwd_prescales_q(Lq, Lk);      // (that kernel always rebuilds pre-scaled scores)
-        if (dq_w64) {
-            static DevFlags wattr_done_tab; DevFlag wattr_done = dev_flag(wattr_done_tab);
-            if (!wattr_done) { const int rc = attn_bwd_dq_w64_prepare(); if (rc != MVIT_OK) return rc; wattr_done = true; }
-            const int rc = attn_bwd_dq_w64_launch(q, k, v, dout, lse, workspace, dq, B, heads, Lq, Lk, scale, sl2, add_q, st);
-            if (rc != MVIT_OK) return rc;
-            MVIT_LAUNCH_CHECK();
-        }
+        // (a 64-queries-per-wave form of pass A was built in round 3 and measured 4-12 % behind this kernel, profiles/r3_attn_dq_w64.txt:
+        // it lives in tools/probes/attention_bwd_w64.hip, outside the library, since round 5)
         dim3 gq((Lq + 127) / 128, B * heads);
         static DevFlags dq_attr_done_tab; DevFlag dq_attr_done = dev_flag(dq_attr_done_tab);
         if (!dq_attr_done) {
@@ -890,8 +865,7 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         const bool pre = attn_fwd_prescales_q(Lq, Lk);
 #define DQ_LAUNCH(AQ, PR) hipLaunchKernelGGL((attn_bwd_dq_kernel<AQ, PR>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k, \
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2)
-        if (dq_w64) {}
-        else if (add_q) { if (pre) DQ_LAUNCH(true, true); else DQ_LAUNCH(true, false); }
+        if (add_q) { if (pre) DQ_LAUNCH(true, true); else DQ_LAUNCH(true, false); }
         else { if (pre) DQ_LAUNCH(false, true); else DQ_LAUNCH(false, false); }
 #undef DQ_LAUNCH
         MVIT_LAUNCH_CHECK();

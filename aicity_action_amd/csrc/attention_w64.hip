@@ -89,29 +89,17 @@ __device__ __forceinline__ void w_for(F&& f) {
 #define W_SB __builtin_amdgcn_sched_barrier(0)
 template <int N> using IC = std::integral_constant<int, N>;
 
-// PARTIAL: the key-split form of ONE query tile (q_tile0, the ragged last tile of every (batch, head)): blockIdx.x is the split, the
-// workgroup visits key tiles [split * nkt / W_KS, (split + 1) * nkt / W_KS) only and leaves its unnormalised O^T, reference point and
-// row sum in the workspace (attn_fwd_merge_kernel combines the W_KS parts).  Which tile is split depends on Lq alone -- never on the
-// batch -- so a row's arithmetic is the same in every launch it appears in.
-#define W_KS 8
-template <bool ADD_Q, bool PARTIAL>
+// (the last two kernel arguments are unused: they belonged to the key-split form of the ragged query tile, tools/probes/attn_fwd_keysplit.patch)
+template <bool ADD_Q>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                               float* __restrict__ LSE, int heads, int Lq, int Lk_all, float scale_log2e,
-                                                              float* __restrict__ WS, int q_tile0) {
+                                                              float* __restrict__ /*unused*/, int /*unused*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int qtile, bh;
     xcd_group_map(qtile, bh);
-    int split = 0, Lk = Lk_all;
-    int64_t key0 = 0;
-    if constexpr (PARTIAL) {
-        split = qtile;
-        qtile = q_tile0;
-        const int nkt_all = (Lk_all + W_KT - 1) / W_KT;
-        const int kt0 = split * nkt_all / W_KS, kt1 = (split + 1) * nkt_all / W_KS;
-        key0 = (int64_t)kt0 * W_KT;
-        Lk = (kt1 * W_KT < Lk_all ? kt1 * W_KT : Lk_all) - kt0 * W_KT;
-    }
+    const int Lk = Lk_all;
+    const int64_t key0 = 0;
     const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -522,27 +510,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
 #endif
     // ---- epilogue: normalise, + q residual, store [b][q][g*96 + d] -------------------------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if constexpr (PARTIAL) {        // this key range's unnormalised O^T (fp32), reference point and row sum -> workspace [bh][split][256 queries]
-        const int64_t unit = (int64_t)bh * W_KS + split;
-        float* wo = WS + unit * (W_QB * 96);
-        float* wml = WS + (int64_t)gridDim.y * W_KS * (W_QB * 96) + unit * (W_QB * 2);
-        w_for<0, 2>([&](auto J) {
-            constexpr int j = J;
-            const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
-            const int ql = wave * 64 + 32 * j + r;
-            if (h == 0) {
-                wml[2 * ql] = m_run[j];
-                wml[2 * ql + 1] = l_tot;
-            }
-            w_for<0, 12>([&](auto I) {
-                constexpr int db = I / 4, i4 = I % 4;
-                float4 v;
-                w_oget4<16 * (3 * j + db) + 4 * i4>(v);
-                *reinterpret_cast<float4*>(wo + ql * 96 + 32 * db + 8 * i4 + 4 * h) = v;
-            });
-        });
-        return;
-    }
     w_for<0, 2>([&](auto J) {
         constexpr int j = J;
         const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
@@ -566,76 +533,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     });
 }
 
-// combines the W_KS parts of the key-split tile: out = sum_s 2^(m_s - m*) O_s / sum_s 2^(m_s - m*) l_s (+ q), lse = m* + log2(sum)
-template <bool ADD_Q>
-__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const float* __restrict__ WS, const bf16_t* __restrict__ Q, bf16_t* __restrict__ O,
-                                                             float* __restrict__ LSE, int heads, int Lq, int q0, int nq, int nbh) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // (bh, query, 4-channel piece)
-    const int piece = idx % 24, ql = (idx / 24) % nq, bh = idx / (24 * nq);
-    if (bh >= nbh) return;
-    const float* wml = WS + (int64_t)nbh * W_KS * (W_QB * 96) + ((int64_t)bh * W_KS) * (W_QB * 2) + 2 * ql;
-    float m[W_KS], l[W_KS], mstar = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < W_KS; ++s) {
-        m[s] = wml[s * (W_QB * 2)];
-        l[s] = wml[s * (W_QB * 2) + 1];
-        mstar = fmaxf(mstar, m[s]);
-    }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float lsum = 0.f;
-#pragma unroll
-    for (int s = 0; s < W_KS; ++s) {
-        const float w = __builtin_amdgcn_exp2f(m[s] - mstar);
-        const float4 o = *reinterpret_cast<const float4*>(WS + (((int64_t)bh * W_KS + s) * W_QB + ql) * 96 + 4 * piece);
-        acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y); acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
-        lsum = fmaf(w, l[s], lsum);
-    }
-    const float inv = 1.0f / lsum;
-    const int b = bh / heads, g = bh - b * heads, qi = q0 + ql;
-    float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    if (ADD_Q) {
-        const float4 qq = load4(Q + ((int64_t)bh * Lq + qi) * 96 + 4 * piece);
-        v.x += qq.x; v.y += qq.y; v.z += qq.z; v.w += qq.w;
-    }
-    store4(O + ((int64_t)b * Lq + qi) * (heads * 96) + g * 96 + 4 * piece, v);
-    if (LSE && piece == 0) LSE[(int64_t)bh * Lq + qi] = mstar + __builtin_amdgcn_logf(lsum);      // log2 domain
-}
-
 int attn_fwd_w64_prepare() { return MVIT_OK; }      // 48 KiB of dynamic LDS: no attribute needed
-
-// The ragged last query tile of every (batch, head) is key-split when there is one (Lq % 256 != 0), the key loop is long enough to
-// split (>= W_KS key tiles) and the caller gave a workspace: at the model's stage 3 (Lq = 6272 = 24.5 tiles, 32 (batch, head) pairs)
-// the main grid is then 768 workgroups = three full rounds of the chip instead of 800 = 3.125.
-bool attn_fwd_w64_splits_tail(int Lq, int Lk) { return (Lq % W_QB) != 0 && Lq > W_QB && (Lk + W_KT - 1) / W_KT >= W_KS; }
-int64_t attn_fwd_w64_workspace_floats(int B, int heads, int Lq, int Lk) {
-    return attn_fwd_w64_splits_tail(Lq, Lk) ? (int64_t)B * heads * W_KS * W_QB * 98 : 0;
-}
 
 // launcher used by mvit_attention_fwd (attention.hip) when this form is selected
 int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads, int Lq, int Lk,
-                        float scale_log2e, int add_q, hipStream_t st, float* ws) {
-    const bool split = ws && attn_fwd_w64_splits_tail(Lq, Lk);
-    dim3 grid(split ? Lq / W_QB : (Lq + W_QB - 1) / W_QB, B * heads);
+                        float scale_log2e, int add_q, hipStream_t st) {
+    dim3 grid((Lq + W_QB - 1) / W_QB, B * heads);
     if (add_q)
-        hipLaunchKernelGGL((attn_fwd_w64_kernel<true, false>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
+        hipLaunchKernelGGL((attn_fwd_w64_kernel<true>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
                            lse, heads, Lq, Lk, scale_log2e, nullptr, 0);
     else
-        hipLaunchKernelGGL((attn_fwd_w64_kernel<false, false>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
+        hipLaunchKernelGGL((attn_fwd_w64_kernel<false>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
                            lse, heads, Lq, Lk, scale_log2e, nullptr, 0);
-    if (split) {
-        if (hipGetLastError() != hipSuccess) return MVIT_ELAUNCH;
-        const int qt = Lq / W_QB, nq = Lq - qt * W_QB;
-        dim3 gt(W_KS, B * heads);
-        hipLaunchKernelGGL((attn_fwd_w64_kernel<false, true>), gt, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
-                           nullptr, heads, Lq, Lk, scale_log2e, ws, qt);
-        if (hipGetLastError() != hipSuccess) return MVIT_ELAUNCH;
-        const int64_t n = (int64_t)B * heads * nq * 24;
-        if (add_q)
-            hipLaunchKernelGGL((attn_fwd_merge_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, (const bf16_t*)q, (bf16_t*)out, lse, heads,
-                               Lq, qt * W_QB, nq, B * heads);
-        else
-            hipLaunchKernelGGL((attn_fwd_merge_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, (const bf16_t*)q, (bf16_t*)out, lse, heads,
-                               Lq, qt * W_QB, nq, B * heads);
-    }
     return MVIT_OK;
 }

@@ -173,8 +173,7 @@ struct MfCfg {
 template <int CB, int TB, bool PROJ>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restrict__ X, const bf16_t* __restrict__ Oa, const char* __restrict__ Wpk,
                                                            const float* __restrict__ B1p, const float* __restrict__ B2, float* __restrict__ Out,
-                                                           int64_t M, int nch, float eps, const float* __restrict__ Gn, const float* __restrict__ Bn,
-                                                           float eps_n, bf16_t* __restrict__ Un) {
+                                                           int64_t M, int nch, float eps) {
     using K = MfCfg<CB, TB>;
     constexpr int NPC = CB;                               // proj chunks (32 output channels each)
     const char* const Wmlp = Wpk + (PROJ ? NPC * K::WU : 0);
@@ -658,97 +657,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const float* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped LDS-DMA pieces of the last iterations)
     __builtin_amdgcn_s_barrier();                          // every wave is done with the rings
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    if (Un != nullptr) {
-        // ---- ... and the NEXT block's norm1 on the rows just finished: u = LayerNorm(out; Gn, Bn) as the 16-bit operand of its qkv GEMM
-        // (attention.py:421): the wave holds whole rows here, the standalone LayerNorm launch (one more read of out) disappears.
-        float* const ex = reinterpret_cast<float*>(smem + 4 * K::ST_PITCH);          // b2 | gamma | beta, fp32 [C] each
-        for (int i = tid; i < 3 * C / 4; i += 256) {
-            const int a = i / (C / 4), j = i - a * (C / 4);
-            const float* src = a == 0 ? B2 : (a == 1 ? Gn : Bn);
-            reinterpret_cast<float4*>(ex)[i] = *reinterpret_cast<const float4*>(src + 4 * j);
-        }
-        __syncthreads();
-        float mean_t[TB], rstd_t[TB];
-        mf_for<0, TB>([&](auto T_) {                 // statistics of out = Y^T + b2, streaming over the accumulators (nothing large in arch VGPRs)
-            constexpr int tb = T_;
-            float sm = 0.f;
-            mf_for<0, CB * 4>([&](auto Q_) {
-                constexpr int cb = Q_ / 4, g = Q_ % 4;
-                float4 a;
-                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
-                sm += ((a.x + bb.x) + (a.y + bb.y)) + ((a.z + bb.z) + (a.w + bb.w));
-            });
-            sm += __shfl_xor(sm, 32, 64);
-            const float mean = sm * (1.0f / C);
-            float qq = 0.f;
-            mf_for<0, CB * 4>([&](auto Q_) {
-                constexpr int cb = Q_ / 4, g = Q_ % 4;
-                float4 a;
-                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
-                const float d0 = a.x + bb.x - mean, d1 = a.y + bb.y - mean, d2 = a.z + bb.z - mean, d3 = a.w + bb.w - mean;
-                qq = fmaf(d0, d0, qq); qq = fmaf(d1, d1, qq); qq = fmaf(d2, d2, qq); qq = fmaf(d3, d3, qq);
-            });
-            qq += __shfl_xor(qq, 32, 64);
-            mean_t[tb] = mean;
-            rstd_t[tb] = 1.0f / sqrtf(qq * (1.0f / C) + eps_n);
-        });
-        constexpr int PRU = K::PR / 2, NIU = K::NI / 2, RPIU = 192 / PRU, RSU = K::SEG / 2 + 16;      // the 16-bit image: half the bytes per row segment
-        static_assert(192 % PRU == 0 && NIU % 3 == 0, "column pattern of the 16-bit side");
-        int row_c[3], col_c[3], row_u[3], col_u[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int q = 64 * c + lane;
-            row_c[c] = q / K::PR;
-            col_c[c] = q - row_c[c] * K::PR;
-            row_u[c] = q / PRU;
-            col_u[c] = q - row_u[c] * PRU;
-        }
-        mf_for<0, TB * K::CP>([&](auto P_) {
-            constexpr int tb = P_ / K::CP, cp = P_ % K::CP, NCB = CB / K::CP;
-            char* wp = st_area + r * K::RS + 16 * h;
-            mf_for<0, NCB * 4>([&](auto Q_) {
-                constexpr int cbl = Q_ / 4, g = Q_ % 4, cb = cp * NCB + cbl;
-                float4 a;
-                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
-                *reinterpret_cast<float4*>(wp + (32 * cbl + 8 * g) * 4) = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mf_for<0, K::NI>([&](auto I_) {
-                constexpr int i = I_, c = i % 3;
-                const int row = row_c[c] + (i / 3) * K::RPI;
-                const float4 a = *reinterpret_cast<const float4*>(st_area + row * K::RS + 16 * col_c[c]);
-                const int64_t t = tok0 + 32 * tb + row;
-                if (t < M) *reinterpret_cast<float4*>(Out + t * C + cp * (C / K::CP) + 4 * col_c[c]) = a;
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            char* wu = st_area + r * RSU + 8 * h;
-            mf_for<0, NCB * 4>([&](auto Q_) {
-                constexpr int cbl = Q_ / 4, g = Q_ % 4, cb = cp * NCB + cbl;
-                const float4 gg = *reinterpret_cast<const float4*>(ex + C + 32 * cb + 8 * g + 4 * h);
-                const float4 be = *reinterpret_cast<const float4*>(ex + 2 * C + 32 * cb + 8 * g + 4 * h);
-                const float m_ = mean_t[tb], rs_ = rstd_t[tb];
-                float4 a;
-                mf_aget4<16 * (cb * TB + tb) + 4 * g>(a);
-                const float4 bb = *reinterpret_cast<const float4*>(ex + 32 * cb + 8 * g + 4 * h);
-                const float u0 = fmaf((a.x + bb.x - m_) * rs_, gg.x, be.x), u1 = fmaf((a.y + bb.y - m_) * rs_, gg.y, be.y);
-                const float u2 = fmaf((a.z + bb.z - m_) * rs_, gg.z, be.z), u3 = fmaf((a.w + bb.w - m_) * rs_, gg.w, be.w);
-                *reinterpret_cast<uint2*>(wu + (32 * cbl + 8 * g) * 2) = make_uint2(pack_bf16x2(u0, u1), pack_bf16x2(u2, u3));
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mf_for<0, NIU>([&](auto I_) {
-                constexpr int i = I_, c = i % 3;
-                const int row = row_u[c] + (i / 3) * RPIU;
-                const uint4 a = *reinterpret_cast<const uint4*>(st_area + row * RSU + 16 * col_u[c]);
-                const int64_t t = tok0 + 32 * tb + row;
-                if (t < M) *reinterpret_cast<uint4*>(Un + t * C + cp * (C / K::CP) + 8 * col_u[c]) = a;
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        });
-        return;
-    }
+    // (round 4 also had an epilogue form that wrote the NEXT block's norm1 from these accumulators -- measured neutral in the model,
+    // taken out in round 5: tools/probes/block_tail_next_u.patch, profiles/r4_ln1_emit_in_model_ab.txt)
     {
         int row_c[3], col_c[3];
 #pragma unroll
@@ -902,8 +812,7 @@ extern "C" int mvit_block_tail_pack(const float* wproj, const float* bproj, cons
 }
 
 template <int CB, int TB, bool PROJ>
-static int mf_launch(const float* x, const void* o, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st,
-                     const float* gn = nullptr, const float* bn = nullptr, float eps_n = 0.f, void* un = nullptr) {
+static int mf_launch(const float* x, const void* o, const void* packed, const float* b2, float* out, int64_t M, int hidden, float eps, hipStream_t st) {
     using K = MfCfg<CB, TB>;
     const int ring = 6 * K::WU + K::B1BYTES + (PROJ ? K::BPBYTES : 0), stage = 4 * K::ST_PITCH + 12 * K::C;       // rings + biases | staging areas (+ b2, gamma, beta of the emitted LayerNorm)
     const int smem = ring > stage ? ring : stage;
@@ -919,8 +828,7 @@ static int mf_launch(const float* x, const void* o, const void* packed, const fl
     const int nch = hidden / 32;
     const char* wpk = reinterpret_cast<const char*>(packed);
     const float* b1p = reinterpret_cast<const float*>(wpk + (PROJ ? (int64_t)CB * K::WU : 0) + (int64_t)nch * K::CHB);
-    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB, PROJ>), dim3((unsigned)tiles), dim3(256), smem, st, x, (const bf16_t*)o, wpk, b1p, b2, out, M, nch, eps, gn, bn,
-                       eps_n, (bf16_t*)un);
+    hipLaunchKernelGGL((mlp_fused_kernel<CB, TB, PROJ>), dim3((unsigned)tiles), dim3(256), smem, st, x, (const bf16_t*)o, wpk, b1p, b2, out, M, nch, eps);
     MVIT_LAUNCH_CHECK();
     return MVIT_OK;
 }
@@ -939,17 +847,15 @@ extern "C" int mvit_mlp_fused_fwd(const float* x, const void* packed, const floa
     }
 }
 extern "C" int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
-                                   int hidden, float eps, const float* next_gamma, const float* next_beta, float next_eps, void* next_u,
-                                   int act_dtype, void* stream) {
+                                   int hidden, float eps, int act_dtype, void* stream) {
     if (!o || !resid || !packed || !b2 || !out || M < 0) return MVIT_EINVAL;
-    if (next_u && (!next_gamma || !next_beta)) return MVIT_EINVAL;
     if (act_dtype != MVIT_BF16) return MVIT_EUNSUPPORTED;
     if (!mf_shape_ok(C, hidden)) return MVIT_EUNSUPPORTED;
     if (M == 0) return MVIT_OK;
     hipStream_t st = as_stream(stream);
     switch (C) {
-        case 384: return mf_launch<12, 1, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
-        case 192: return mf_launch<6, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
-        default: return mf_launch<3, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st, next_gamma, next_beta, next_eps, next_u);
+        case 384: return mf_launch<12, 1, true>(resid, o, packed, b2, out, M, hidden, eps, st);
+        case 192: return mf_launch<6, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
+        default: return mf_launch<3, 2, true>(resid, o, packed, b2, out, M, hidden, eps, st);
     }
 }

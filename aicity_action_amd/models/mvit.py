@@ -94,10 +94,6 @@ _FINITE_GUARDS = weakref.WeakKeyDictionary()     # model -> (device flag, event)
 _MLP_FUSE = os.environ.get("MVIT_MLP_FUSE", "1") != "0"
 # ... with the attention output projection in front of it (mvit_block_tail_fwd); MVIT_TAIL_FUSE=0 keeps proj as its own launch
 _TAIL_FUSE = os.environ.get("MVIT_TAIL_FUSE", "1") != "0"
-# ... and, on request (MVIT_LN1_FUSE=1), the next block's norm1 written by the same kernel.  Built, parity-tested, measured neutral inside
-# the model (profiles/r4_ln1_emit_in_model_ab.txt: 697-698 against 701-702 clips/s: what the 15 LayerNorm launches cost, the tail's longer
-# epilogue costs again on the three sub-batch streams): off by default
-_LN1_FUSE = os.environ.get("MVIT_LN1_FUSE", "0") == "1"
 
 
 @MODEL_REGISTRY.register()
@@ -423,10 +419,8 @@ class MViT(nn.Module):
                                    B, T, S, act, st), "stem")
         if taps is not None:
             taps["stem"] = x
-        u = None                                   # norm1 of the coming block, when the previous block's fused tail has already written it
-        for i, (g, blk) in enumerate(zip(self.geoms, self.blocks)):
-            nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
-            x, u = self._block_fwd(L, st, act, adt, g, blk, x, B, taps, u, nxt)
+        for g, blk in zip(self.geoms, self.blocks):
+            x = self._block_fwd(L, st, act, adt, g, blk, x, B, taps)
             if taps is not None:
                 taps["block%d" % g.index] = x
         C = self.geoms[-1].dim_out
@@ -503,8 +497,8 @@ class MViT(nn.Module):
                    "linear %dx%dx%d" % (M, N, K))
         return y
 
-    def _block_fwd(self, L, st, act, adt, g, blk, x, B, taps=None, u=None, nxt=None):
-        """One block; returns (x_out, u_next): u_next = norm1 of block `nxt` on x_out when this block's fused tail wrote it, else None."""
+    def _block_fwd(self, L, st, act, adt, g, blk, x, B, taps=None):
+        """One block (inference path); returns x_out [B, Lq, Cout] fp32."""
         dev = x.device
         T, H, W = g.thw_in
         N = g.n_in
@@ -512,10 +506,9 @@ class MViT(nn.Module):
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         at = blk.attn
         # 1. U = LN1(x)                                                   attention.py:421
-        if u is None:
-            u = torch.empty(M, Cin, dtype=adt, device=dev)
-            _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
-                                            Cin, blk.norm1.eps, act, st), "norm1")
+        u = torch.empty(M, Cin, dtype=adt, device=dev)
+        _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
+                                        Cin, blk.norm1.eps, act, st), "norm1")
         # 2. fused qkv projection, kept token-major [B,N,3*Cout]          attention.py:230-236
         qkv = self._linear(L, st, act, u, act, at.qkv, adt, M)
         del u
@@ -576,15 +569,9 @@ class MViT(nn.Module):
         tk = self._tail_packed(blk, act)
         if tk is not None:
             out = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
-            un, n1 = None, None
-            if nxt is not None and _LN1_FUSE and tuple(nxt.norm1.weight.shape) == (Cout,):
-                n1 = nxt.norm1                          # the next block's norm1 leaves with this kernel's rows
-                un = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
             _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o), _hip.ptr(r), _hip.ptr(tk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out), B * Lq, Cout,
-                                             blk.mlp.fc1.weight.shape[0], blk.norm2.eps, _hip.ptr(n1.weight) if n1 is not None else None,
-                                             _hip.ptr(n1.bias) if n1 is not None else None, n1.eps if n1 is not None else 0.0, _hip.ptr(un), act, st),
-                       "block_tail")
-            return out.view(B, Lq, Cout), un
+                                             blk.mlp.fc1.weight.shape[0], blk.norm2.eps, act, st), "block_tail")
+            return out.view(B, Lq, Cout)
         # 6. y = r + proj(o)                                                 attention.py:281,434
         y = self._linear(L, st, act, o, act, at.proj, torch.float32, B * Lq, residual=r)
         del o, r
@@ -594,11 +581,11 @@ class MViT(nn.Module):
             out = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_mlp_fused_fwd(_hip.ptr(y), _hip.ptr(pk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out), B * Lq, Cout,
                                             blk.mlp.fc1.weight.shape[0], blk.norm2.eps, act, st), "mlp_fused")
-            return out.view(B, Lq, Cout), None
+            return out.view(B, Lq, Cout)
         vn = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
         _hip.check(L.mvit_layernorm_fwd(_hip.ptr(y), _hip.ptr(blk.norm2.weight), _hip.ptr(blk.norm2.bias), _hip.ptr(vn),
                                         B * Lq, Cout, blk.norm2.eps, act, st), "norm2")
         hid = self._linear(L, st, act, vn, act, blk.mlp.fc1, adt, B * Lq, gelu=True)
         del vn
         out = self._linear(L, st, act, hid, act, blk.mlp.fc2, torch.float32, B * Lq, residual=y)
-        return out.view(B, Lq, Cout), None
+        return out.view(B, Lq, Cout)

@@ -339,7 +339,7 @@ def main():
                     r_ = torch.randn(Mt, Ct, device=dev)
                     out_ = torch.empty_like(r_)
                     ms = timed(lambda: _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o_), _hip.ptr(r_), _hip.ptr(tk), _hip.ptr(blk.mlp.fc2.bias), _hip.ptr(out_), Mt, Ct,
-                                                                         4 * Ct, blk.norm2.eps, None, None, 0.0, None, act, st)))
+                                                                         4 * Ct, blk.norm2.eps, act, st)))
                     fl_t = 18.0 * Mt * Ct * Ct
                     ach = fl_t / (ms * 1e-3) / 1e12
                     extra_rooflines["roofline_block_tail"] = {

@@ -90,15 +90,12 @@ int mvit_mlp_fused_fwd(const float* x, const void* packed, const float* b2, floa
  * y never reaches HBM: the accumulators start at resid, the projection accumulates onto them, LayerNorm is taken from them.
  *   packed: mvit_block_tail_pack_bytes(C, hidden) bytes written by mvit_block_tail_pack: the proj weight as C/32 chunk images, the
  *           mvit_mlp_fused_pack image, the proj bias.  wproj fp32 [C][C].  Same shape limits as mvit_mlp_fused_fwd.
- *   next_u (NULL = off): act-typed [M][C] receiving LayerNorm(out; next_gamma, next_beta, next_eps) -- the following block's norm1
- *           (attention.py:421), the operand of its qkv GEMM: the kernel holds whole rows at its end, so the standalone LayerNorm launch
- *           of the next block (one more read of out) is not needed. */
+ */
 int64_t mvit_block_tail_pack_bytes(int C, int hidden);
 int mvit_block_tail_pack(const float* wproj, const float* bproj, const float* w1, const float* b1, const float* gamma,
                          const float* beta, const float* w2, void* packed, int C, int hidden, void* stream);
 int mvit_block_tail_fwd(const void* o, const float* resid, const void* packed, const float* b2, float* out, int64_t M, int C,
-                        int hidden, float eps, const float* next_gamma, const float* next_beta, float next_eps, void* next_u,
-                        int act_dtype, void* stream);
+                        int hidden, float eps, int act_dtype, void* stream);
 
 /* Pooling conv + LayerNorm of one of q/k/v for all heads (attention_pool, conv variant:
  * slowfast/models/attention.py:12-83 with the Conv3d of :172-212 and LayerNorm(eps 1e-5) of
@@ -116,15 +113,6 @@ int mvit_pool_conv_ln_fwd(const void* qkv, int64_t ld, int chan_off, const float
  * lse: NULL, or fp32 [B][heads][Lq] receiving log2(sum_k exp(score)) (saved for the backward pass). */
 int mvit_attention_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
-/* The same with a caller-provided workspace (>= mvit_attention_fwd_workspace_bytes; 0 = none needed for this shape): when Lq is not a
- * multiple of 256 the ragged last query tile of every (batch, head) is computed key-split over 8 workgroups and merged, so the main
- * grid is whole tiles only (stage 3 @448, B = 8: 768 workgroups = 3 rounds of the chip instead of 3.125).  Which rows are split
- * depends on Lq alone, never on B: a row's result is the same in every batch it appears in.  workspace NULL = mvit_attention_fwd. */
-int64_t mvit_attention_fwd_workspace_bytes(int B, int heads, int Lq, int Lk, int act_dtype);
-int mvit_attention_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads,
-                          int Lq, int Lk, float scale, int add_q, int act_dtype, float* workspace, int64_t workspace_bytes,
-                          void* stream);
-
 /* Skip-path MaxPool3d k(1,3,3) s(1,2,2) p(0,1,1) on the token grid (slowfast/models/attention.py:
  * 316-318,389-395,427-432); x fp32 [B][T*H*W][C] -> y fp32 [B][T*Ho*Wo][C]. */
 int mvit_maxpool_skip_fwd(const float* x, float* y, int B, int T, int H, int W, int C, void* stream);
@@ -213,13 +201,6 @@ int64_t mvit_attention_bwd_workspace_bytes(int B, int heads, int Lq, int Lk);
 int mvit_attention_bwd(const void* q, const void* k, const void* v, const void* out, const float* lse,
                        const void* dout, void* dq, void* dk, void* dv, float* workspace, int B, int heads,
                        int Lq, int Lk, float scale, int add_q, int act_dtype, void* stream);
-/* The opt-in 64-query form of the dQ pass by itself (MVIT_ATT_DQ_W64=1 selects it inside mvit_attention_bwd; measured behind the
- * default 32-query pass, kept for A/B runs and its parity test).  16-bit builds only, Lk >= 64.  delta: fp32 [B*heads*Lq] =
- * rowsum(dout * out), i.e. the head of the workspace mvit_attention_bwd has filled.  (slowfast/models/attention.py:267-279) */
-int mvit_attention_bwd_dq_w64(const void* q, const void* k, const void* v, const void* dout, const float* lse,
-                              const float* delta, void* dq, int B, int heads, int Lq, int Lk, float scale, int add_q,
-                              void* stream);
-
 /* Backward of mvit_pool_conv_ln_fwd: dout [B][heads][T*Ho*Wo][96] -> the (which) slice of dqkv [B][T*H*W][ld]
  * (fully overwritten), dw [96][27] (accumulated), dgamma/dbeta.  dconv: scratch shaped like dout.
  * workspace >= mvit_pool_bwd_workspace_bytes(B, heads, T, H, W, stride_hw). */

@@ -1,4 +1,4 @@
-"""CPU: the kernels that own ACC registers by name in their asm text (csrc/attention_w64.hip, attention_bwd_w64.hip, mlp_fused.hip) are compiled to
+"""CPU: the kernels that own ACC registers by name in their asm text (csrc/attention_w64.hip, mlp_fused.hip) are compiled to
 assembly for both 16-bit builds and audited the way cdna_hip_programming.md section 5.7 item 4 asks after every edit: the compiler must
 not touch an ACC register itself (a spill into a[0:239] is silent corruption of the accumulators), must not spill, must not use scratch.
 """
@@ -41,7 +41,7 @@ def _audit(args):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_asm_owned_acc_registers_are_left_alone_by_the_compiler():
-    jobs = [(s, d) for s in ("attention_w64.hip", "attention_bwd_w64.hip", "mlp_fused.hip") for d in ("", "-DMVIT_HALF_IS_FP16")]
+    jobs = [(s, d) for s in ("attention_w64.hip", "mlp_fused.hip") for d in ("", "-DMVIT_HALF_IS_FP16")]
     with ThreadPoolExecutor(4) as ex:
         results = list(ex.map(_audit, jobs))
     for src, define, bad, spills, scratch, kernels in results:

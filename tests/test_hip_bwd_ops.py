@@ -262,35 +262,6 @@ def test_attention_bwd_rows_with_a_dominant_key(hip_lib, c):
     _close(dk, kr.grad, 2e-2)
 
 
-@pytest.mark.parametrize("B,h,Lq,Lk,add_q", [(1, 1, 256, 200, 1), (1, 2, 257, 392, 0), (2, 1, 300, 1568, 1), (1, 1, 5000, 256, 1)])
-def test_attention_bwd_dq_64_query_form(hip_lib, B, h, Lq, Lk, add_q):
-    """The 64-queries-per-wave form of the dQ pass (csrc/attention_bwd_w64.hip; opt-in, MVIT_ATT_DQ_W64=1) against autograd and against
-    the default pass on the same operands: ragged key tiles (masked keys start at -inf), partial workgroups, both residual modes."""
-    scale = 96 ** -0.5
-    q, k, v = (_rnd(B, h, n, 96, seed=sd).to(torch.bfloat16) for n, sd in ((Lq, 61), (Lk, 62), (Lk, 63)))
-    do = _rnd(B, Lq, h * 96, seed=64).to(torch.bfloat16)
-    qr = q.float().requires_grad_(True)
-    o = ((qr @ k.float().transpose(-2, -1)) * scale).softmax(-1) @ v.float()
-    if add_q:
-        o = o + qr
-    o.transpose(1, 2).reshape(B, Lq, h * 96).backward(do.float())
-    qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
-    out = torch.empty(B, Lq, h * 96, dtype=torch.bfloat16, device=DEV)
-    lse = torch.empty(B, h, Lq, device=DEV)
-    _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk, scale, add_q,
-                                          _hip.BF16, _st()))
-    dq0, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    ws = torch.empty(hip_lib.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk) // 4, device=DEV)
-    _hip.check(hip_lib.mvit_attention_bwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), _hip.ptr(dod), _hip.ptr(dq0),
-                                          _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, scale, add_q, _hip.BF16, _st()))
-    fn = hip_lib.mvit_attention_bwd_dq_w64          # delta = the head of the workspace mvit_attention_bwd has just filled
-    dq1 = torch.full_like(qd, float("nan"))
-    _hip.check(fn(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(dod), _hip.ptr(lse), _hip.ptr(ws), _hip.ptr(dq1), B, h, Lq, Lk, scale, add_q,
-                  _st()))
-    _close(dq1, qr.grad, 2e-2)
-    _close(dq1, dq0.float().cpu(), 1e-2)
-
-
 @pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 1, 5, 9, 96)])
 def test_maxpool_skip_bwd(hip_lib, B, T, H, W, C):
     x = _rnd(B, T * H * W, C, seed=23).requires_grad_(True)

@@ -23,7 +23,7 @@ out = torch.empty_like(res)
 if mode == "tail":
     pk = torch.empty(L.mvit_block_tail_pack_bytes(C, hid), dtype=torch.uint8, device=dev)
     _hip.check(L.mvit_block_tail_pack(*[_hip.ptr(t) for t in (wp, bp, w1, b1, gam, bet, w2)], _hip.ptr(pk), C, hid, st()))
-    fn = lambda: _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o), _hip.ptr(res), _hip.ptr(pk), _hip.ptr(b2), _hip.ptr(out), M, C, hid, 1e-6, None, None, 0.0, None,
+    fn = lambda: _hip.check(L.mvit_block_tail_fwd(_hip.ptr(o), _hip.ptr(res), _hip.ptr(pk), _hip.ptr(b2), _hip.ptr(out), M, C, hid, 1e-6,
                                                    _hip.BF16, st()))
     flop = 16.0 * M * C * C + 2.0 * M * C * C
 else:
