@@ -135,7 +135,11 @@ def _cfg_dump(cfg):
 
 
 def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, scaler=None):
-    """Master process only; returns the path (checkpoint.py:107-139)."""
+    """Master process only; returns the path (checkpoint.py:107-139).  A sharded optimizer (solver.HipZeroAdamW) first gathers its
+    moments on the master: that is a collective, so every rank enters here (the reference's loop calls save_checkpoint on all ranks,
+    train_net.py:747-759, and returns early on the others)."""
+    if hasattr(optimizer, "consolidate_state_dict"):
+        optimizer.consolidate_state_dict(0)
     if du.get_rank() != 0:
         return None
     os.makedirs(get_checkpoint_dir(path_to_job), exist_ok=True)

@@ -61,24 +61,35 @@ class HipAdamW(object):
     """AdamW(betas (0.9, 0.999), eps 1e-8) with fused global-norm clipping, fp32 state."""
 
     def __init__(self, model, cfg):
-        if cfg.SOLVER.OPTIMIZING_METHOD != "adamw":
+        if cfg.SOLVER.OPTIMIZING_METHOD not in ("adamw", "zero_adamw"):
             raise NotImplementedError("Does not support {} optimizer".format(cfg.SOLVER.OPTIMIZING_METHOD))
         self.cfg = cfg
         self.lr = cfg.SOLVER.BASE_LR
         self.betas = (0.9, 0.999)
         self.eps = 1e-8
         self.step_count = 0
-        decay, no_decay = param_groups(model, cfg)
-        self.groups = [{"params": [p for _, p in decay], "names": [n for n, _ in decay], "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
-                       {"params": [p for _, p in no_decay], "names": [n for n, _ in no_decay], "weight_decay": 0.0}]
+        self.groups = self._make_groups(model, cfg)
+        self._owned = self._ownership()          # None: this rank updates every parameter; else the set it owns (HipZeroAdamW)
         self.state = {}
         for grp in self.groups:
             for p in grp["params"]:
-                self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format),
-                                 torch.zeros_like(p, memory_format=torch.contiguous_format))
+                if self._owned is None or p in self._owned:
+                    self.state[p] = (torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                     torch.zeros_like(p, memory_format=torch.contiguous_format))
         self._table = None
         self._grad_ptrs = None
         self.last_grad_norm = None
+
+    def _make_groups(self, model, cfg):
+        decay, no_decay = param_groups(model, cfg)
+        return [{"params": [p for _, p in decay], "names": [n for n, _ in decay], "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
+                {"params": [p for _, p in no_decay], "names": [n for n, _ in no_decay], "weight_decay": 0.0}]
+
+    def _ownership(self):
+        return None
+
+    def _after_update(self):
+        pass
 
     def set_lr(self, lr):
         self.lr = float(lr)
@@ -96,19 +107,25 @@ class HipAdamW(object):
 
     def _build(self):
         self.table_builds = getattr(self, "table_builds", 0) + 1      # each build is an H2D copy = a host sync (see step())
-        rec, ptrs = [], []
+        rec, rec_other, ptrs = [], [], []
         for grp in self.groups:
             for p in grp["params"]:
                 if p.grad is None:            # torch.optim skips parameters that received no gradient this step
                     ptrs.append(0)
                     continue
                 assert p.grad.is_contiguous() and p.is_contiguous() and p.dtype == torch.float32
-                m, v = self.state[p]
+                mine = self._owned is None or p in self._owned
+                m, v = self.state[p] if mine else (None, None)
                 n = p.numel()
                 ptrs.append(p.grad.data_ptr())
                 for off in range(0, n, _CHUNK):
-                    rec.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, m.data_ptr() + 4 * off,
-                                v.data_ptr() + 4 * off, min(_CHUNK, n - off), grp["weight_decay"]))
+                    (rec if mine else rec_other).append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off,
+                                                         m.data_ptr() + 4 * off if mine else 0, v.data_ptr() + 4 * off if mine else 0,
+                                                         min(_CHUNK, n - off), grp["weight_decay"]))
+        # the chunks this rank UPDATES come first: the norm kernel walks the whole table (every rank holds every gradient after DDP's
+        # all-reduce, so the global norm and the clip coefficient are the same everywhere), the AdamW kernel only the first _n_upd
+        self._n_upd = len(rec)
+        rec = rec + rec_other
         dev = self.groups[0]["params"][0].device
         assert _hip.lib().mvit_mt_chunk_bytes() == _DT.itemsize
         host = np.array(rec, dtype=_DT).view(np.uint8)
@@ -211,12 +228,15 @@ class HipAdamW(object):
         else:
             _hip.check(L.mvit_grad_norm(_hip.ptr(self._table), self._n, float(max_norm), _hip.ptr(self._partials),
                                         _hip.ptr(self._out2), st), "grad_norm")
+        n_upd = self._n_upd
         if hyper is not None:       # per-iteration scalars from device memory (captured step)
-            _hip.check(L.mvit_adamw_step_dev(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), _hip.ptr(hyper), self.betas[0],
-                                             self.betas[1], self.eps, st), "adamw")
-        else:
-            _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), self._n, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
+            if n_upd:
+                _hip.check(L.mvit_adamw_step_dev(_hip.ptr(self._table), n_upd, _hip.ptr(self._out2), _hip.ptr(hyper), self.betas[0],
+                                                 self.betas[1], self.eps, st), "adamw")
+        elif n_upd:
+            _hip.check(L.mvit_adamw_step(_hip.ptr(self._table), n_upd, _hip.ptr(self._out2), self.lr, self.betas[0], self.betas[1],
                                          self.eps, self.step_count, st), "adamw")
+        self._after_update()
         self.last_grad_norm = self._out2      # device tensor [norm, coef]; no host sync here
         # the kernel wrote the parameters behind torch's back: bump their version counters so every version-keyed cache (the
         # 16-bit / transposed GEMM weight copies of MViT._w and autograd._Ctx.wt) is refreshed on the next use
@@ -234,8 +254,9 @@ class HipAdamW(object):
         for grp in self.groups:
             ids = []
             for p in grp["params"]:
-                m, v = self.state[p]
-                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+                if p in self.state:          # (HipZeroAdamW: only this rank's shard, until consolidate_state_dict() has run)
+                    m, v = self.state[p]
+                    state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
                 ids.append(idx)
                 idx += 1
             groups.append({"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": grp["weight_decay"], "amsgrad": False,
@@ -260,7 +281,7 @@ class HipAdamW(object):
         for grp in self.groups:
             for p in grp["params"]:
                 ent = sd["state"].get(idx)
-                if ent is not None:            # torch omits entries of parameters that never received a gradient
+                if ent is not None and p in self.state:     # torch omits entries of parameters that never received a gradient
                     self.state[p][0].copy_(ent["exp_avg"])
                     self.state[p][1].copy_(ent["exp_avg_sq"])
                     self.step_count = int(float(ent["step"]))
@@ -323,7 +344,76 @@ class HipGradScaler(object):
         self._growth_interval, self._growth_tracker = int(sd["growth_interval"]), int(sd["_growth_tracker"])
 
 
+class HipZeroAdamW(HipAdamW):
+    """``SOLVER.OPTIMIZING_METHOD zero_adamw`` (slowfast/models/optimizer.py:189-199: ``ZeroRedundancyOptimizer(model.parameters(),
+    optimizer_class=AdamW, ...)``): ZeRO stage 1.  Every rank keeps the AdamW moments of ITS shard of the parameters only (greedy
+    partition by size, as torch's ZeroRedundancyOptimizer does), updates that shard with the same fused kernels, and the owners
+    broadcast their updated parameters (one flat buffer per owner).  Gradients are complete on every rank (DDP all-reduce), so the
+    global-norm clip needs no extra collective.  As in the reference, this path hands ``model.parameters()`` to the optimizer in ONE
+    group: the weight decay applies to every parameter, 1-D ones included (optimizer.py:190-191 prints exactly that warning).
+    ``state_dict()`` holds this rank's shard until ``consolidate_state_dict()`` (a collective: every rank calls it) has gathered the
+    rest on rank ``to``; ``engine.save_checkpoint`` calls it."""
+
+    def _make_groups(self, model, cfg):
+        mod = model.module if hasattr(model, "module") else model
+        named = [(n, p) for n, p in mod.named_parameters() if p.requires_grad]
+        if cfg.SOLVER.ZERO_WD_1D_PARAM:
+            import logging
+            logging.getLogger(__name__).warning("warning, not setting zero parameters weight decay to zero")     # optimizer.py:190-191
+        return [{"params": [p for _, p in named], "names": [n for n, _ in named], "weight_decay": cfg.SOLVER.WEIGHT_DECAY}]
+
+    def _ownership(self):
+        from . import distributed as du
+        self.rank, self.world = du.get_rank(), du.get_world_size()
+        params = [p for g in self.groups for p in g["params"]]
+        load = [0] * self.world
+        self.owner = {}
+        for i in sorted(range(len(params)), key=lambda i: (-params[i].numel(), i)):     # largest first onto the least loaded rank
+            r = min(range(self.world), key=lambda r_: (load[r_], r_))
+            self.owner[params[i]] = r
+            load[r] += params[i].numel()
+        self.shards = [[p for p in params if self.owner[p] == r] for r in range(self.world)]
+        return set(self.shards[self.rank])
+
+    def _after_update(self):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        for r, shard in enumerate(self.shards):
+            if not shard:
+                continue
+            flat = _flatten_dense_tensors([p.data for p in shard])
+            dist.broadcast(flat, src=r)
+            if r != self.rank:
+                for p, new in zip(shard, _unflatten_dense_tensors(flat, [p.data for p in shard])):
+                    p.data.copy_(new)
+
+    def consolidate_state_dict(self, to=0):
+        """Gathers every shard's moments on rank ``to`` (collective).  Afterwards ``state_dict()`` on that rank is the full
+        ``torch.optim.AdamW`` layout."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        for r, shard in enumerate(self.shards):
+            for p in shard:
+                if r == to:
+                    continue
+                if self.rank == r:
+                    dist.send(torch.stack(list(self.state[p])), dst=to)
+                elif self.rank == to:
+                    buf = torch.empty((2,) + tuple(p.shape), dtype=p.dtype, device=p.device)
+                    dist.recv(buf, src=r)
+                    self.state[p] = (buf[0], buf[1])
+        if self.rank == to:
+            self._consolidated = True
+
+
 def construct_optimizer(model, cfg):
+    """slowfast/models/optimizer.py:14-206 for the methods the MViT recipes use: ``adamw`` (the README recipe; parameter groups of
+    :56-75) and ``zero_adamw`` (:189-199); anything else raises NotImplementedError as the reference does for unknown names."""
+    if cfg.SOLVER.OPTIMIZING_METHOD == "zero_adamw":
+        return HipZeroAdamW(model, cfg)
     return HipAdamW(model, cfg)
 
 

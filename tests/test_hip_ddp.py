@@ -366,3 +366,89 @@ def test_ddp_two_ranks_at_the_benchmark_configuration_with_stochastic_ops():
           % (rel_all, worst, worst_name, out["loss"], float(loss.detach()), stream_warn or "none about streams"))
     assert rel_all <= 2e-3
     assert not stream_warn, stream_warn
+
+
+def _zero_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.solver import HipZeroAdamW, construct_optimizer, soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z, meta = load_golden("tiny_even")
+    cfg = cfg_for_case(meta, "fp32", train=True)
+    cfg.NUM_GPUS = 1
+    cfg.SOLVER.OPTIMIZING_METHOD = "zero_adamw"
+    model = build_model(cfg, gpu_id=0).train()
+    load_synth_weights(model, 0)
+    opt = construct_optimizer(model, cfg)
+    assert isinstance(opt, HipZeroAdamW) and opt.world == world
+    mine = sum(p.numel() for p in opt.state)
+    total = sum(p.numel() for p in model.parameters())
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    labels = torch.from_numpy(z["train.labels"]).cuda()
+    for _ in range(2):                                  # the same batch on both ranks: identical gradients, as after DDP's all-reduce
+        opt.set_lr(1e-3)
+        loss = soft_target_cross_entropy(model([clip]), labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    opt.consolidate_state_dict(0)
+    sd = opt.state_dict()
+    q.put((rank, mine, total, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}, len(sd["state"]),
+           {i: e["exp_avg_sq"].cpu().numpy() for i, e in sd["state"].items()} if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero_adamw_two_ranks_matches_torch_adamw():
+    """SOLVER.OPTIMIZING_METHOD zero_adamw (slowfast/models/optimizer.py:189-199: ZeroRedundancyOptimizer over AdamW, ONE parameter group,
+    i.e. weight decay on every parameter): two ranks each keep the moments of their shard only (about half the elements), update it
+    with the fused kernels and broadcast; after two clipped steps both ranks hold the parameters torch.optim.AdamW + clip_grad_norm_
+    produce in one process, and the consolidated state on rank 0 has every parameter's moments."""
+    import torch.multiprocessing as mp
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.solver import soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, mine0, total, par0, n0, vsq0), (_, mine1, _, par1, n1, _) = got
+    assert mine0 + mine1 == total and abs(mine0 - mine1) <= 0.2 * total        # a real partition, roughly balanced
+    z, meta = load_golden("tiny_even")
+    cfg = cfg_for_case(meta, "fp32", train=True)
+    cfg.NUM_GPUS = 1
+    model = build_model(cfg).train()
+    load_synth_weights(model, 0)
+    ref = torch.optim.AdamW(model.parameters(), lr=1e-3, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY)     # one group: decay everywhere
+    clip = synth_clip(meta["batch"], meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    labels = torch.from_numpy(z["train.labels"]).cuda()
+    for _ in range(2):
+        loss = soft_target_cross_entropy(model([clip]), labels)
+        ref.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)
+        ref.step()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        a = p.detach().cpu().numpy()
+        assert np.array_equal(par0[k], par1[k]), "ranks disagree on " + k
+        worst = max(worst, float(np.abs(par0[k] - a).max()))
+    print("ZeRO AdamW (2 ranks) vs torch.optim.AdamW after 2 clipped steps: max parameter difference %.2e; shard sizes %d + %d of %d" % (worst, mine0, mine1, total))
+    # Adam's first steps move every element by about lr whatever its gradient: elements whose gradient is at the fp32 noise floor
+    # can differ by a fraction of lr between two implementations (1.0e-5 observed at lr 1e-3, two steps)
+    assert worst <= 3e-5
+    nparams = len(list(model.parameters()))
+    assert n0 == nparams and n1 < nparams and len(vsq0) == nparams
+    tstate = [ref.state[p]["exp_avg_sq"].cpu().numpy() for p in model.parameters()]
+    assert max(float(np.abs(vsq0[i] - tstate[i]).max()) for i in range(nparams)) <= 1e-6
