@@ -939,7 +939,9 @@ int mvit_internal_pool_dgrad2_tiled_kv(const void* dconv_kv, const float* w_k, c
 // pool_march.hip: the march form of the weight gradient (16-bit builds: v_dot2c over token pairs, 7 x 7 tiles); MVIT_POOL_WGRAD_MARCH=0
 // keeps the 8-wide tiles below (A/B)
 int mvit_internal_pool_wgrad_march(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads, int T, int H,
-                                   int W, int stride_hw, int nset, hipStream_t st);
+                                   int W, int stride_hw, int nset, hipStream_t st, const void* xhat = nullptr, const void* dout = nullptr,
+                                   const float* rstd = nullptr, const float* gamma = nullptr, const float* gamma2 = nullptr,
+                                   float* part_ln = nullptr);
 static bool wgrad_march_on() {
     static const bool on = !(getenv("MVIT_POOL_WGRAD_MARCH") && getenv("MVIT_POOL_WGRAD_MARCH")[0] == '0');
     return on;

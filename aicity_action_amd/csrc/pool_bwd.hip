@@ -19,6 +19,9 @@ int mvit_internal_pool_wgrad_tiled(const void* qkv, int64_t ld, int chan_off, co
                                    int T, int H, int W, int stride_hw, int act_dtype, hipStream_t st);
 int mvit_internal_pool_dgrad2_tiled_kv(const void* dconv_kv, const float* w_k, const float* w_v, void* dqkv, int64_t ld, int chan_off_k,
                                        int B, int heads, int T, int H, int W, int act_dtype, hipStream_t st);
+int mvit_internal_pool_wgrad_march(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads, int T, int H,
+                                   int W, int stride_hw, int nset, hipStream_t st, const void* xhat, const void* dout, const float* rstd,
+                                   const float* gamma, const float* gamma2, float* part_ln);      // pool_march.hip (xhat != null: LayerNorm backward fused in front)
 int mvit_internal_pool_wgrad_tiled_kv(const void* qkv, int64_t ld, int chan_off_k, const void* dconv_kv, float* part, int B, int heads,
                                       int T, int H, int W, int act_dtype, hipStream_t st);
 int mvit_internal_pool_ln_bwd_tiled(const void* qkv, int64_t ld, int chan_off, const float* w, const float* gamma, const void* dout,
@@ -330,20 +333,27 @@ __global__ __launch_bounds__(1024) void pool_wgrad_kernel(const TA* __restrict__
     }
 }
 
-// geometry-aware size (the tiled LN-backward writes one 192-float partial row per tile workgroup)
-extern "C" int64_t mvit_pool_bwd_workspace_bytes(int B, int heads, int T, int H, int W, int stride_hw) {
+// Workspace layout of the pooling-conv backward, ONE formula for the size query and for the entry points (round 5: the two had their own
+// copies, and a change to one of them overran the allocation): [prow][192] LayerNorm partial rows | [wrows][2592] weight-gradient rows.
+//   prow : one row per workgroup of whichever form runs -- the row-wise LayerNorm backward (<= 2048 blocks, clamped to prow), the 8-wide
+//          tiled form (exact-fp32 path), the fused LayerNorm-backward + weight-gradient march kernel (one per 7 x 7 tile)
+//   wrows: one row per workgroup of the weight-gradient kernel -- generic (<= PW_MAXBLK), 8-wide tiles, 7 x 7 tiles
+static void pool_bwd_rows(int B, int heads, int H, int W, int stride_hw, int64_t& prow, int64_t& wrows) {
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
-    int64_t rows = PB_MAXBLK;
-    if (stride_hw == 1) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
-    if (stride_hw == 2) rows = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
-    if (rows < PB_MAXBLK) rows = PB_MAXBLK;
+    prow = PB_MAXBLK;
+    if (stride_hw == 1) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
+    if (stride_hw == 2) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
+    int64_t mrows = 0;
+    if (stride_hw == 1 || stride_hw == 2) mrows = (int64_t)((Wo + 6) / 7) * ((Ho + 6) / 7) * B * heads;
+    if (mrows > prow) prow = mrows;
+    if (prow < PB_MAXBLK) prow = PB_MAXBLK;
+    wrows = prow > PW_MAXBLK ? prow : PW_MAXBLK;
+}
+extern "C" int64_t mvit_pool_bwd_workspace_bytes(int B, int heads, int T, int H, int W, int stride_hw) {
     (void)T;
-    int64_t wrows = rows > PW_MAXBLK ? rows : PW_MAXBLK;    // tiled wgrad: one [2592] partial row per tile workgroup
-    if (stride_hw == 1 || stride_hw == 2) {                 // ... of the 8-wide tiles or of the 7 x 7 tiles of the march form, whichever is more
-        const int64_t mrows = (int64_t)((Wo + 6) / 7) * ((Ho + 6) / 7) * B * heads;
-        if (mrows > wrows) wrows = mrows;
-    }
-    return (rows * 192 + wrows * 2592) * (int64_t)sizeof(float);
+    int64_t prow, wrows;
+    pool_bwd_rows(B, heads, H, W, stride_hw, prow, wrows);
+    return (prow * 192 + wrows * 2592) * (int64_t)sizeof(float);
 }
 
 // Data gradient for strides >= 3: the 3x3 spatial footprints of neighbouring outputs do not overlap, so an input token (t, y, x)
@@ -536,10 +546,8 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     if (b2 > 16384) b2 = 16384;
     int64_t b3 = (tot_out + 31) / 32;        // the per-lane token loop is a chain of dependent loads: many short blocks (<= PW_MAXBLK partial rows)
     if (b3 > PW_MAXBLK) b3 = PW_MAXBLK;
-    int64_t prow = PB_MAXBLK;
-    if (stride_hw == 1) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 7) / 8) * B * heads;
-    if (stride_hw == 2) prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;
-    if (prow < PB_MAXBLK) prow = PB_MAXBLK;
+    int64_t prow, wrows_;
+    pool_bwd_rows(B, heads, H, W, stride_hw, prow, wrows_);
     float* wpart = workspace + prow * 192;     // layout of mvit_pool_bwd_workspace_bytes
     const bool tiled = stride_hw == 1 || stride_hw == 2;
     static const bool dgrad_tiled = getenv("MVIT_POOL_DGRAD_GATHER") == nullptr;
@@ -548,10 +556,32 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
     static const bool pool_bwd_side = getenv("MVIT_POOL_BWD_SIDE") != nullptr && getenv("MVIT_POOL_BWD_SIDE")[0] == '1';
     // d_conv is complete after the first kernel; the conv weight gradient (+ its partial-row reduction) only reads it, so it is
     // issued on the library's side stream and runs beside the d_gamma / d_beta reductions and the data gradient
+    // saved statistics + 16-bit build + stride 1 / 2: LayerNorm backward and conv weight gradient in ONE kernel (pool_march.hip); MVIT_POOL_LNB_FUSE=0
+    // keeps the row-wise pass + the plain weight-gradient kernel (A/B)
+    // (the fused kernel holds 162 registers at stride 1: one workgroup per CU instead of two, which costs what the saved pass returns on the
+    // large stride-1 grids -- 107 vs 110 us at 28 x 28, 204 vs 214 at 56 x 56 -- so it takes stride 2, where LDS allows one workgroup per CU
+    // either way, and the <= 14 x 14 grids; the rule depends on the geometry alone, never on the batch.  1 = everywhere, 0 = nowhere)
+    static const int lnb_mode = getenv("MVIT_POOL_LNB_FUSE") ? atoi(getenv("MVIT_POOL_LNB_FUSE")) : 2;
+    const bool lnb_fuse = lnb_mode == 1 || (lnb_mode == 2 && (stride_hw == 2 || (int64_t)Ho * Wo <= 196));
+    bool fused_done = false;
+    if (xhat && tiled && act_dtype == MVIT_BF16 && lnb_fuse) {
+        const int wr = mvit_internal_pool_wgrad_march(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw, 1, st, xhat, dout, rstd, gamma,
+                                                      nullptr, workspace);
+        if (wr >= 0) {
+            int rr_ = launch_pool_reduce(workspace, wr, 192, dgamma, dbeta, 96, accumulate_param, st, 1);
+            if (rr_ != MVIT_OK) return rr_;
+            rr_ = launch_pool_reduce(wpart, wr, 2592, dw, dw, 2592, 1, st, 1);
+            if (rr_ != MVIT_OK) return rr_;
+            fused_done = true;
+        } else if (wr != MVIT_EUNSUPPORTED) {
+            return wr;
+        }
+    }
 #define RUN(TA)                                                                                                            \
     SideStream* ss = nullptr;                                                                                              \
     hipStream_t sw = st;                                                                                                   \
-    if (xhat) {                                                                                                            \
+    if (fused_done) {                                                                                                      \
+    } else if (xhat) {                                                                                                     \
         int64_t bs = (tot_out + 63) / 64;       /* as many blocks as the workspace has partial rows for (>= PB_MAXBLK) */  \
         bs = bs > prow ? prow : bs;                                                                                        \
         bs = bs > 2048 ? 2048 : bs;                                                                                        \
@@ -579,7 +609,8 @@ extern "C" int mvit_pool_conv_ln_bwd_saved(const void* qkv, int64_t ld, int chan
         if (ss && side_fork(ss, st)) sw = ss->side;                                                                        \
         { const int rr_ = launch_pool_reduce(workspace, (int)b1, 192, dgamma, dbeta, 96, accumulate_param, st); if (rr_ != MVIT_OK) return rr_; } \
     }                                                                                                                      \
-    if (tiled) {                                                                                                           \
+    if (fused_done) {                                                                                                      \
+    } else if (tiled) {                                                                                                    \
         const int wr = mvit_internal_pool_wgrad_tiled(qkv, ld, chan_off, dconv, wpart, B, heads, T, H, W, stride_hw,        \
                                                       act_dtype, sw);                                                      \
         if (wr < 0) return wr;                                                                                             \
@@ -630,12 +661,29 @@ extern "C" int mvit_pool_conv_ln_bwd_saved_kv(const void* qkv, int64_t ld, int c
     hipStream_t st = as_stream(stream);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int64_t tot_out = (int64_t)B * heads * T * Ho * Wo;            // tokens of ONE tensor
-    int64_t prow = (int64_t)((Wo + 7) / 8) * ((Ho + 3) / 4) * B * heads;   // rows of mvit_pool_bwd_workspace_bytes, per tensor
-    if (prow < PB_MAXBLK) prow = PB_MAXBLK;
+    int64_t prow, wrows_;                   // rows of mvit_pool_bwd_workspace_bytes, per tensor
+    pool_bwd_rows(B, heads, H, W, 2, prow, wrows_);
     int64_t bs = (tot_out + 63) / 64;
     bs = bs > prow ? prow : bs;
     bs = bs > 2048 ? 2048 : bs;
     float* wpart = workspace + 2 * prow * 192;
+    static const bool lnb_fuse_kv = !(getenv("MVIT_POOL_LNB_FUSE") && getenv("MVIT_POOL_LNB_FUSE")[0] == '0');
+    if (act_dtype == MVIT_BF16 && lnb_fuse_kv) {      // LayerNorm backward + weight gradient of both tensors in one launch (pool_march.hip)
+        const int wr = mvit_internal_pool_wgrad_march(qkv, ld, chan_off_k, dconv_kv, wpart, B, heads, T, H, W, 2, 2, st, xhat_kv, dout_kv, rstd_kv,
+                                                      gamma_k, gamma_v, workspace);
+        if (wr >= 0) {            // rows are set-major: the first wr / 2 belong to k
+            int rc2 = launch_pool_reduce(workspace, wr / 2, 192, dgamma_k, dbeta_k, 96, accumulate_param, st, 1);
+            if (rc2 != MVIT_OK) return rc2;
+            rc2 = launch_pool_reduce(workspace + (int64_t)(wr / 2) * 192, wr / 2, 192, dgamma_v, dbeta_v, 96, accumulate_param, st, 1);
+            if (rc2 != MVIT_OK) return rc2;
+            rc2 = launch_pool_reduce(wpart, wr / 2, 2592, dw_k, dw_k, 2592, 1, st, 1);
+            if (rc2 != MVIT_OK) return rc2;
+            rc2 = launch_pool_reduce(wpart + (int64_t)(wr / 2) * 2592, wr / 2, 2592, dw_v, dw_v, 2592, 1, st, 1);
+            if (rc2 != MVIT_OK) return rc2;
+            return mvit_internal_pool_dgrad2_tiled_kv(dconv_kv, w_k, w_v, dqkv, ld, chan_off_k, B, heads, T, H, W, act_dtype, st);
+        }
+        if (wr != MVIT_EUNSUPPORTED) return wr;
+    }
 #define RUNKV(TA)                                                                                                                  \
     hipLaunchKernelGGL((pool_ln_bwd_saved_kernel<TA>), dim3((unsigned)bs, 2), dim3(256), 0, st, (const TA*)xhat_kv, rstd_kv, gamma_k, \
                        (const TA*)dout_kv, (TA*)dconv_kv, workspace, tot_out, gamma_v);                                            \

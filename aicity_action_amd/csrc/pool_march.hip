@@ -383,10 +383,20 @@ __device__ __forceinline__ float dot2_16(uint32_t a, uint32_t b, float c) {
 __device__ __forceinline__ uint32_t pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-template <int S>
+// LNB = true: the LayerNorm BACKWARD of the pooled tensor rides in front (round 5): instead of d_conv the kernel reads what the training
+// forward saved (xhat, rstd) and the incoming gradient dout, forms d_conv = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)) for its 7
+// tokens per frame in registers (two transposed wave reductions), rounds it to the 16-bit type exactly as the separate pass did, WRITES
+// it (the data-gradient kernel reads it next), uses it for the weight gradient, and keeps the per-lane sums of d_gamma = sum dy xhat and
+// d_beta = sum dy, which leave as one [192] partial row per workgroup next to the [2592] one.  The row-wise pass of pool_bwd.hip
+// (one more read of xhat / dout, one more write + read of d_conv, one more launch) disappears.
+template <int S, bool LNB>
 __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __restrict__ in, int64_t ld, int chan_off,
                                                                const bf16_t* __restrict__ dconv, float* __restrict__ part, int heads,
-                                                               int T, int H, int W, int Ho, int Wo, int set_bh) {
+                                                               int T, int H, int W, int Ho, int Wo, int set_bh,
+                                                               const bf16_t* __restrict__ xhat, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ gamma2, bf16_t* __restrict__ dconv_out,
+                                                               float* __restrict__ part_ln) {
     using P = March<bf16_t, S>;
     constexpr int ES = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -434,13 +444,28 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
     // 16 idle lanes, whose sums therefore stay zero)
     const int yo = ty0 + row;
     const bool row_ok = yo < Ho;
-    const uint32_t* drow = reinterpret_cast<const uint32_t*>(dconv + ((int64_t)bh * T * Ho * Wo + (int64_t)(row_ok ? yo : 0) * Wo + tx0) * 96) + cp;
+    const int64_t tok0 = (int64_t)bh * T * Ho * Wo + (int64_t)(row_ok ? yo : 0) * Wo + tx0;      // token index of (frame 0, row yo, x = tx0)
+    const uint32_t* drow = reinterpret_cast<const uint32_t*>((LNB ? dout : dconv) + tok0 * 96) + cp;
+    const uint32_t* hrow = LNB ? reinterpret_cast<const uint32_t*>(xhat + tok0 * 96) + cp : nullptr;
     const int64_t dframe = (int64_t)Ho * Wo * 48;      // dwords per output frame
-    uint32_t raw[P::XO];
+    uint32_t raw[P::XO], rawh[LNB ? P::XO : 1];
+    float rs_l = 0.f;                                  // LNB: rstd of token x in lane x
+    float lg0 = 0.f, lg1 = 0.f, dga0 = 0.f, dga1 = 0.f, dbe0 = 0.f, dbe1 = 0.f;
+    if constexpr (LNB) {
+        const float* gm = (set_bh > 0 && bh >= set_bh) ? gamma2 : gamma;
+        lg0 = gm[2 * cp]; lg1 = gm[2 * cp + 1];
+    }
     auto load_d = [&](int fo) {
         const uint32_t* p = drow + fo * dframe;
 #pragma unroll
         for (int x = 0; x < P::XO; ++x) raw[x] = (tx0 + x < Wo) ? p[x * 48] : 0u;      // (clamped-address form: the test only picks the value)
+        if constexpr (LNB) {
+            const uint32_t* ph = hrow + fo * dframe;
+#pragma unroll
+            for (int x = 0; x < P::XO; ++x) rawh[x] = (tx0 + x < Wo) ? ph[x * 48] : 0u;
+            const int lx = lane < P::XO && tx0 + lane < Wo ? lane : 0;
+            rs_l = rstd[tok0 + (int64_t)fo * Ho * Wo + lx];
+        }
     };
     uint32_t pd[3][4][2];       // [output frame % 3][token pair][channel of the lane's pair]
 #pragma unroll
@@ -448,9 +473,41 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) pd[s][k][0] = pd[s][k][1] = 0u;
     const uint32_t keep = (live && row_ok) ? 0xffffffffu : 0u;
-    auto convert = [&](auto SLOT, bool ok) {       // raw -> token-pair registers of slot SLOT (zeros for a frame outside [0, T))
+    auto convert = [&](auto SLOT, bool ok, int fo) {       // raw -> token-pair registers of slot SLOT (zeros for a frame outside [0, T))
         constexpr int s = decltype(SLOT)::value;
         const uint32_t m = ok ? keep : 0u;
+        if constexpr (LNB) {
+            if (ok) {                                      // wave-uniform: raw = dout, rawh = xhat of output frame fo -> raw = d_conv
+                // (the unpacked values are formed twice -- once for the sums, once for the result -- rather than kept: 42 registers fewer,
+                // which is what keeps two workgroups per CU at stride 1)
+                float p1[P::XO], p2[P::XO], q1[2], q2[2];
+                const float kf = keep ? 1.f : 0.f;
+#pragma unroll
+                for (int x = 0; x < P::XO; ++x) {
+                    const float y0 = lo16_to_f32(raw[x]) * kf, y1 = hi16_to_f32(raw[x]) * kf;      // (tokens outside the grid loaded 0)
+                    const float h0 = lo16_to_f32(rawh[x]), h1 = hi16_to_f32(rawh[x]);
+                    dga0 = fmaf(y0, h0, dga0); dga1 = fmaf(y1, h1, dga1);
+                    dbe0 += y0; dbe1 += y1;
+                    const float g0 = y0 * lg0, g1 = y1 * lg1;
+                    p1[x] = g0 + g1;
+                    p2[x] = fmaf(g0, h0, g1 * h1);
+                }
+                wave_sum_rows<P::XO>(p1, q1);
+                wave_sum_rows<P::XO>(p2, q2);
+                q1[0] *= (1.0f / 96.0f); q1[1] *= (1.0f / 96.0f);
+                q2[0] *= (1.0f / 96.0f); q2[1] *= (1.0f / 96.0f);
+                bf16_t* dc = dconv_out + (tok0 + (int64_t)fo * Ho * Wo) * 96 + 2 * cp;
+#pragma unroll
+                for (int x = 0; x < P::XO; ++x) {
+                    const float c1 = wave_sum_pick(q1, x), c2 = wave_sum_pick(q2, x);
+                    const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), x));
+                    const float g0 = lo16_to_f32(raw[x]) * kf * lg0, g1 = hi16_to_f32(raw[x]) * kf * lg1;
+                    const float h0 = lo16_to_f32(rawh[x]), h1 = hi16_to_f32(rawh[x]);
+                    raw[x] = pack_bf16x2(r * (g0 - c1 - h0 * c2), r * (g1 - c1 - h1 * c2));
+                    if (keep && tx0 + x < Wo) *reinterpret_cast<uint32_t*>(dc + x * 96) = raw[x];
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             pd[s][k][0] = pair_lo(raw[2 * k], raw[2 * k + 1]) & m;
@@ -460,7 +517,7 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
         pd[s][3][1] = (raw[6] >> 16) & m;
     };
     load_d(0);
-    convert(std::integral_constant<int, 0>{}, true);
+    convert(std::integral_constant<int, 0>{}, true, 0);
     if (T > 1) load_d(1);
 
     float acc[27][2];
@@ -472,7 +529,7 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // input frame f (this wave's pieces) and the d_conv registers of frame f+1
         __builtin_amdgcn_s_barrier();
         const int cur = P::NBUF == 2 ? (f & 1) : 0;
-        convert(std::integral_constant<int, (ph + 1) % 3>{}, f + 1 < T);     // d_conv frame f+1 (tap dt = 0) replaces frame f-2
+        convert(std::integral_constant<int, (ph + 1) % 3>{}, f + 1 < T, f + 1);     // d_conv frame f+1 (tap dt = 0) replaces frame f-2
         if (P::NBUF == 2 && f + 1 < T) dma(f + 1, cur ^ 1);
         if (f + 2 < T) load_d(f + 2);
         const char* tile = smem + cur * P::IN_BYTES + cp * 2 * ES;
@@ -536,29 +593,49 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
         const int c = i / 27, t = i - c * 27;          // output index c * 27 + tap (the layout pool_reduce and the conv weight share)
         prow[i] = red[t * 96 + c];
     }
+    if constexpr (LNB) {                               // d_gamma | d_beta of the workgroup's tokens: rows added in row order, [192] per workgroup
+        float* rl = red;                               // (the [tap][96] slab has been read out)
+        for (int r = 0; r < P::ROWS; ++r) {
+            __builtin_amdgcn_s_barrier();
+            if (row == r && live) {
+                float2 a = make_float2(dga0, dga1), b2_ = make_float2(dbe0, dbe1);
+                float2* pa = reinterpret_cast<float2*>(&rl[2 * cp]);
+                float2* pb = reinterpret_cast<float2*>(&rl[96 + 2 * cp]);
+                if (r > 0) { const float2 oa = *pa, ob = *pb; a.x += oa.x; a.y += oa.y; b2_.x += ob.x; b2_.y += ob.y; }
+                *pa = a; *pb = b2_;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tid < 192) part_ln[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 192 + tid] = rl[tid];
+    }
 }
 
 // weight-gradient partial rows, march form: returns the number of rows written ([2592] each), MVIT_EUNSUPPORTED for shapes it does not take
 int mvit_internal_pool_wgrad_march(const void* qkv, int64_t ld, int chan_off, const void* dconv, float* part, int B, int heads, int T, int H,
-                                   int W, int stride_hw, int nset, hipStream_t st) {
+                                   int W, int stride_hw, int nset, hipStream_t st, const void* xhat, const void* dout, const float* rstd,
+                                   const float* gamma, const float* gamma2, float* part_ln) {
+    // xhat != nullptr: the fused form (LayerNorm backward in front): `dconv` is then an OUTPUT, part_ln receives [rows][192]
     if (stride_hw != 1 && stride_hw != 2) return MVIT_EUNSUPPORTED;
     if ((int64_t)H * W * ld * 2 >= (1ll << 31)) return MVIT_EUNSUPPORTED;
     const int Ho = (H - 1) / stride_hw + 1, Wo = (W - 1) / stride_hw + 1;
     dim3 grid(((Wo + 6) / 7) * ((Ho + 6) / 7), nset * B * heads);
-#define WG_LAUNCH(S)                                                                                                                      \
+#define WG_LAUNCH(S, LNB)                                                                                                                 \
     {                                                                                                                                     \
         using P = March<bf16_t, S>;                                                                                                       \
         constexpr int SM = P::NBUF * P::IN_BYTES;                                                                                         \
         static DevFlags attr_tab; DevFlag attr_done = dev_flag(attr_tab);                                                                 \
         if (!attr_done) {                                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_march_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess) \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_march_kernel<S, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess) \
                 return MVIT_ELAUNCH;                                                                                                      \
             attr_done = true;                                                                                                             \
         }                                                                                                                                 \
-        hipLaunchKernelGGL((pool_wgrad_march_kernel<S>), grid, dim3(P::NT), SM, st, (const bf16_t*)qkv, ld, chan_off, (const bf16_t*)dconv, \
-                           part, heads, T, H, W, Ho, Wo, nset == 2 ? B * heads : 0);                                                      \
+        hipLaunchKernelGGL((pool_wgrad_march_kernel<S, LNB>), grid, dim3(P::NT), SM, st, (const bf16_t*)qkv, ld, chan_off, (const bf16_t*)dconv, \
+                           part, heads, T, H, W, Ho, Wo, nset == 2 ? B * heads : 0, (const bf16_t*)xhat, (const bf16_t*)dout, rstd, gamma, \
+                           gamma2, (bf16_t*)const_cast<void*>(dconv), part_ln);                                                           \
     }
-    if (stride_hw == 1) WG_LAUNCH(1) else WG_LAUNCH(2)
+    if (xhat) { if (stride_hw == 1) WG_LAUNCH(1, true) else WG_LAUNCH(2, true) }
+    else { if (stride_hw == 1) WG_LAUNCH(1, false) else WG_LAUNCH(2, false) }
 #undef WG_LAUNCH
     MVIT_LAUNCH_CHECK();
     return (int)(grid.x * grid.y);
