@@ -1,20 +1,24 @@
 // Pooling conv (depthwise 3x3x3, stride (1,S,S), zero pad 1, one 96-channel kernel shared by all heads) + LayerNorm(96),
-// spatial strides 1 and 2 (98 % of the pooled tokens): the "march" kernel.
+// spatial strides 1 and 2 (98 % of the pooled tokens): the "march" kernels -- forward (inference / training), the stride-1 data
+// gradient, and (at the end of the file) the weight gradient with the LayerNorm backward optionally fused in front.
 //   reference: attention_pool, slowfast/models/attention.py:12-83 (conv variant) with norm_{q,k,v} of :185,199,213.
 //
-// HBM-bound op (192 B in + 192 B out per token at stride 1) that the first version ran at 18 % of the HBM rate because every
-// frame paid an exposed global-load round trip, four workgroup barriers and an fp32 LDS round trip for the LayerNorm.
-// Structure here:
+// fp32-VALU-bound op (27 taps x 96 channels per token against 192 B in + 192 B out at stride 1; DESIGN.md section 8b has the
+// counters and ablations).  Structure:
 //   * workgroup = 7 waves = a 7 x 7 output tile of one (batch, head); wave = one output row, lane = one channel PAIR (48 of
 //     the 64 lanes carry data; every token grid of the model -- 112, 56, 28, 14, 7 -- is a multiple of 7, so no tile is partial);
+//     blockIdx.y >= set_bh selects a SECOND tensor (the k / v pair of a block: adjacent head groups of the fused qkv buffer, own
+//     conv weights and LayerNorm parameters, outputs back to back) -- one launch of 2 x B x heads x tiles workgroups;
 //   * the workgroup marches over the T input frames; a frame's halo tile (IH x IW tokens x 96 channels) arrives in LDS by
 //     global_load_lds (inline asm: SGPR frame base + 32-bit lane offset), double-buffered so the next frame is in flight under
 //     the current frame's arithmetic; halo cells outside the image are zeroed once and never written again;
-//   * three rolling accumulator sets (output frames f-1, f, f+1): each LDS value is read once per dy and used for 9 taps,
-//     arithmetic in plain v_fma_f32 (measured: the packed v_pk_fma_f32 form of the same loop ran slower);
-//   * the LayerNorm of a finished frame runs IN REGISTERS: the 96 channels of a token are the 48 lanes of one wave, so mean and
-//     variance are two 64-lane butterflies (DPP quad_perm / row_half_mirror / row_mirror, ds_swizzle xor 16, v_permlane32_swap)
-//     -- no LDS stage, no barrier, all lanes busy; one s_barrier per frame in total.
+//   * three rolling accumulator sets (output frames f-1, f, f+1) with COMPILE-TIME names: the frame body is instantiated for
+//     the three phases f mod 3, nothing is copied when the window moves; each LDS value is read once per dy and used for 9
+//     taps, arithmetic in plain v_fma_f32 (v_fma_mix_f32 in the fp16 build: the compiler folds the unpack), the 27 weight
+//     reads per input row stay LDS reads (common.h::lds_opaque -- laundering the generic pointer made them FLAT loads);
+//   * the LayerNorm of a finished frame runs IN REGISTERS: the 96 channels of a token are the 48 lanes of one wave; the sums
+//     of a frame's 7 tokens are folded into each other (wave_sum_rows: v_permlane32_swap, v_permlane16_swap, 4 DPP levels on two
+//     registers) and the per-token scalars fetched by v_readlane -- no LDS stage, no barrier; one s_barrier per frame in total.
 // MODE 0: forward.  MODE 1: training forward, also writes xhat = (conv - mean) * rstd and rstd (what the LayerNorm backward
 // needs).  MODE 2 ("plain", stride 1): the bare convolution with mirrored taps written token-major into a channel slice of a
 // [B][tokens][out_ld] buffer = the DATA gradient of the stride-1 pooling conv (attention.py:56 backward).
