@@ -180,12 +180,17 @@ __device__ __forceinline__ bf16x8 b_join(bf16x4 lo, bf16x4 hi) {
 
 // PRE: the forward of this shape ran on round16(q * scale * log2e) (attn_fwd_prescales_q): rebuild exactly those scores.  Otherwise
 // the forward's scores were (q . k) * scale * log2e on the unrounded q, and so are these (one multiply-add per element more).
-template <bool ADD_Q, bool PRE = true>
+// FD (round 5): this pass also PRODUCES delta and the pre-scaled queries instead of reading delta: it holds its query's dO half-row in
+// registers anyway, so it loads the matching half-row of the forward output, forms delta = sum_d dO (O - q) itself (two lanes per query:
+// one v_add across lane ^ 32) and writes delta and round16(q * scale_log2e) for the dK/dV pass behind it on the same stream.  The
+// separate delta kernel (a read of dO, O, q and a write of the scaled q: 154 MB per stage-3 call, 35 us) is then not launched.
+template <bool ADD_Q, bool PRE = true, bool FD = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                              const float* __restrict__ LSE, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dQ, int heads, int Lq, int Lk, float scale,
-                                                             float scale_log2e) {
+                                                             float scale_log2e, const bf16_t* __restrict__ O = nullptr,
+                                                             float* __restrict__ delta_out = nullptr, bf16_t* __restrict__ Qs = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // BQ_STAGES x (K rotation image | V rotation image)
     int qtile, bh;
     xcd_group_map(qtile, bh);
@@ -245,7 +250,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         dof[ks] = *reinterpret_cast<const bf16x8*>(dOrow + 16 * ks + 8 * h);
     }
     float lse = LSE[(int64_t)bh * Lq + qi];
-    float dlt = delta[(int64_t)bh * Lq + qi];
+    float dlt;
+    if constexpr (FD) {
+        const bf16_t* Orow = O + ((int64_t)b * Lq + qi) * C + g * 96;
+        bf16x8 of[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) of[ks] = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * h);
+        float sp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o = bf16_to_f32((bf16_t)of[ks][e]);
+                if (ADD_Q) o -= bf16_to_f32((bf16_t)qf[ks][e]);          // the forward output carries the pooled-q residual: delta is on the attention part
+                sp = fmaf(bf16_to_f32((bf16_t)dof[ks][e]), o, sp);
+            }
+        dlt = sp + __shfl_xor(sp, 32, 64);                               // the two lanes of a query hold its two half-rows
+        if (q_ok && h == 0) delta_out[(int64_t)bh * Lq + qi] = dlt;
+    } else {
+        dlt = delta[(int64_t)bh * Lq + qi];
+    }
     // consume the register operands once: their vmcnt wait is paid here, not inside the loop
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
@@ -257,6 +281,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         for (int ks = 0; ks < 6; ++ks) {
             const uint4 u = make_uint4(scl(qf[ks][0], qf[ks][1]), scl(qf[ks][2], qf[ks][3]), scl(qf[ks][4], qf[ks][5]), scl(qf[ks][6], qf[ks][7]));
             qf[ks] = *reinterpret_cast<const bf16x8*>(&u);
+        }
+        if constexpr (FD) {              // ... and leave them for the dK/dV pass, whose query tiles go from memory to LDS without passing through registers
+            if (Qs != nullptr && q_ok) {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) *reinterpret_cast<bf16x8*>(Qs + ((int64_t)bh * Lq + qi) * 96 + 16 * ks + 8 * h) = qf[ks];
+            }
         }
     }
     asm volatile("" : "+v"(lse), "+v"(dlt));
@@ -828,7 +858,14 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         // 2^(s * 2^-9): dV errors of 1-2 % instead of 0.3 %, tools/probes/attn_peaked.py.)
         bf16_t* qs = (flat_delta && attn_fwd_prescales_q(Lq, Lk))
                          ? reinterpret_cast<bf16_t*>(workspace + ws_qs_offset_floats(B, heads, Lq, Lk)) : nullptr;
-        if (flat_delta) {
+        // Lk <= 2048 (13 of the 16 blocks): dQ and dK/dV run one after the other on this stream, and the dQ pass produces delta and the scaled
+        // queries itself (FD form above) -- no delta launch.  The three long-key blocks keep the delta kernel: their two passes run side by side,
+        // both need delta at their start.  MVIT_ATT_DELTA_FUSE=0 keeps the separate kernel everywhere (A/B).
+        static const bool fd_env = !(getenv("MVIT_ATT_DELTA_FUSE") && getenv("MVIT_ATT_DELTA_FUSE")[0] == '0');
+        static const char* side_env0 = getenv("MVIT_ATT_BWD_SIDE");
+        const bool fuse_delta = fd_env && flat_delta && !(side_env0 ? side_env0[0] == '1' : Lk > 2048);
+        if (fuse_delta) {
+        } else if (flat_delta) {
             const int64_t nchunks = rows * 12;
             int64_t fb = (nchunks + 191) / 192;
             if (fb > 8192) fb = 8192;
@@ -853,7 +890,11 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         dim3 gq((Lq + 127) / 128, B * heads);
         static DevFlags dq_attr_done_tab; DevFlag dq_attr_done = dev_flag(dq_attr_done_tab);
         if (!dq_attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BQ_STAGES * BQ_TILEB) != hipSuccess)
@@ -865,9 +906,15 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         const bool pre = attn_fwd_prescales_q(Lq, Lk);
 #define DQ_LAUNCH(AQ, PR) hipLaunchKernelGGL((attn_bwd_dq_kernel<AQ, PR>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k, \
                                (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2)
-        if (add_q) { if (pre) DQ_LAUNCH(true, true); else DQ_LAUNCH(true, false); }
+#define DQ_LAUNCH_FD(AQ, PR) hipLaunchKernelGGL((attn_bwd_dq_kernel<AQ, PR, true>), gq, dim3(256), BQ_STAGES * BQ_TILEB, st, (const bf16_t*)q, (const bf16_t*)k, \
+                               (const bf16_t*)v, (const bf16_t*)dout, lse, workspace, (bf16_t*)dq, heads, Lq, Lk, scale, sl2, (const bf16_t*)out, workspace, qs)
+        if (fuse_delta) {
+            if (add_q) { if (pre) DQ_LAUNCH_FD(true, true); else DQ_LAUNCH_FD(true, false); }
+            else { if (pre) DQ_LAUNCH_FD(false, true); else DQ_LAUNCH_FD(false, false); }
+        } else if (add_q) { if (pre) DQ_LAUNCH(true, true); else DQ_LAUNCH(true, false); }
         else { if (pre) DQ_LAUNCH(false, true); else DQ_LAUNCH(false, false); }
 #undef DQ_LAUNCH
+#undef DQ_LAUNCH_FD
         MVIT_LAUNCH_CHECK();
         static DevFlags dkv_attr_done_tab; DevFlag dkv_attr_done = dev_flag(dkv_attr_done_tab);
         if (!dkv_attr_done) {
