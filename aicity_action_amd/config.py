@@ -124,7 +124,7 @@ def _defaults():
         # bf16 gradient payload: 70.6 MB instead of 141 MB per step over xGMI).  STAT_QUEUE_DEPTH: iterations the training loop may
         # run ahead of the GPU before it waits for a step's scalars (meters.DeviceScalarQueue).  GRAPH_STEP: engine.train_epoch
         # captures the whole train step in a hipGraph after two eager iterations and replays it (graph_step.py)
-        "HIP": {"PRECISION": "auto", "STREAMS": 2, "TRAIN_STREAMS": 1, "WGRAD_STREAM": True, "DDP_BUCKET_VIEW": True,
+        "HIP": {"PRECISION": "auto", "STREAMS": 3, "TRAIN_STREAMS": 1, "WGRAD_STREAM": True, "DDP_BUCKET_VIEW": True,
                 "DDP_STATIC_GRAPH": True, "DDP_BF16_GRADS": False, "STAT_QUEUE_DEPTH": 2, "GRAPH_STEP": False,
                 "REL_POS_BIAS": False},
     }

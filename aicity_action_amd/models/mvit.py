@@ -352,12 +352,13 @@ class MViT(nn.Module):
 
     @property
     def eval_streams(self):
-        """HIP.STREAMS (default 2 since round 4: with the fused block tail -- one 4-wave workgroup per CU -- two 4-clip sub-batches measured
-        709-711 clips/s against 698-700 for three at B=8 @448, profiles/r4_streams_2_vs_3.txt; rounds 1-3: 3): inference batches are processed as this many sub-batches on separate HIP streams, so one
-        sub-batch's kernels fill the partially occupied last wave of workgroups of the others' (two streams +7 % at B=8 @448, three another
-        +1 ... 4 %: profiles/r3_final2_fwd_streams.txt)."""
+        """HIP.STREAMS (default 3): inference batches are processed as this many sub-batches on separate HIP streams, so one sub-batch's kernels
+        fill the partially occupied last wave of workgroups of the others' (two streams +13 % over one at B=8 @448, three another +2 %).
+        History of the default: 3 in rounds 1-3; 2 in round 4 (with the fused block tail -- one 4-wave workgroup per CU -- two 4-clip
+        sub-batches measured 709-711 clips/s against 698-700 for three, profiles/r4_streams_2_vs_3.txt); 3 again since round 5: with the
+        7-wave pooling-conv workgroups five interleaved pairs read 713 against 699 clips/s (profiles/r5_streams_2_vs_3_b.txt)."""
         hip = getattr(self.cfg, "HIP", None)
-        return int(getattr(hip, "STREAMS", 2)) if hip is not None else 2
+        return int(getattr(hip, "STREAMS", 3)) if hip is not None else 3
 
     @property
     def train_streams(self):

@@ -24,14 +24,16 @@ for m in train fwd; do
 done
 # HBM traffic (PMC, separate passes): attention kernels as bench.py times them, and the fused block tail at the stage-3 shape
 rm -rf gpurun_out/traffic
+MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd3_hbm_traffic.json --mode fwd --precision bf16 --batch 9 --streams 3 > /dev/null 2>&1
+rm -rf gpurun_out/traffic
 MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd4_hbm_traffic.json --mode fwd --precision bf16 --streams 2 > /dev/null 2>&1
 rm -rf gpurun_out/traffic
 MARKER=attn_fwd tools/traffic.sh attn_fwd gpurun_out/${pre}_attn_fwd8_hbm_traffic.json --mode fwd --precision bf16 --streams 1 > /dev/null 2>&1
 rm -rf gpurun_out/traffic
-MARKER=attn_bwd_delta tools/traffic.sh attn_bwd gpurun_out/${pre}_attn_bwd_hbm_traffic.json --mode train > /dev/null 2>&1
+MARKER=attn_bwd_dq_kernel tools/traffic.sh attn_bwd gpurun_out/${pre}_attn_bwd_hbm_traffic.json --mode train > /dev/null 2>&1
 rm -rf gpurun_out/traffic
 cd /tmp && export TMPDIR=/tmp
-for shp in "50176 384" "25088 384"; do
+for shp in "50176 384" "25088 384" "18816 384"; do
   tag=$(echo $shp | tr ' ' 'x')
   rm -rf $root/gpurun_out/tt
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/tt/f -- python3 $root/tools/block_tail_bench.py $shp tail 5 > /dev/null 2>&1
@@ -59,7 +61,7 @@ PY
   rm -rf $root/gpurun_out/tt
 done
 cd $root
-(for shp in "50176 384" "25088 384"; do python3 tools/block_tail_bench.py $shp tail 20; python3 tools/block_tail_bench.py $shp mlp 20; done) 2>&1 | grep -v amdgpu > gpurun_out/${pre}_block_tail_alone.txt
+(for shp in "50176 384" "25088 384" "18816 384"; do python3 tools/block_tail_bench.py $shp tail 20; python3 tools/block_tail_bench.py $shp mlp 20; done) 2>&1 | grep -v amdgpu > gpurun_out/${pre}_block_tail_alone.txt
 (for st in 1 2 3 4; do echo "HIP.STREAMS $st fwd fp16: $(python bench.py --mode fwd --streams $st --no-cpu-baseline --steps 40 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])')"; done) > gpurun_out/${pre}_fwd_streams.txt 2>&1
 # HBM traffic of the two stem kernels (PMC, separate passes)
 cd /tmp && export TMPDIR=/tmp
