@@ -462,11 +462,11 @@ __global__ __launch_bounds__(448) void pool_wgrad_march_kernel(const bf16_t* __r
     auto load_d = [&](int fo) {
         const uint32_t* p = drow + fo * dframe;
 #pragma unroll
-        for (int x = 0; x < P::XO; ++x) raw[x] = (tx0 + x < Wo) ? p[x * 48] : 0u;      // (clamped-address form: the test only picks the value)
+        for (int x = 0; x < P::XO; ++x) raw[x] = (tx0 + x < Wo) ? p[(tx0 + x < Wo ? x : 0) * 48] : 0u;      // (the address is clamped into the row: the compiler may hoist the load over the test)
         if constexpr (LNB) {
             const uint32_t* ph = hrow + fo * dframe;
 #pragma unroll
-            for (int x = 0; x < P::XO; ++x) rawh[x] = (tx0 + x < Wo) ? ph[x * 48] : 0u;
+            for (int x = 0; x < P::XO; ++x) rawh[x] = (tx0 + x < Wo) ? ph[(tx0 + x < Wo ? x : 0) * 48] : 0u;
             const int lx = lane < P::XO && tx0 + lane < Wo ? lane : 0;
             rs_l = rstd[tok0 + (int64_t)fo * Ho * Wo + lx];
         }
