@@ -74,7 +74,11 @@ def main():
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         bias = torch.randn(N, device=dev)
         aux = torch.randn(M, N, device=dev).bfloat16()
-        y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        # OPB_Y_PAD=<bytes>: the second matrix starts this many bytes behind a 2 MiB boundary (the allocator hands out 2 MiB-aligned blocks, so
+        # element (m, n) of both matrices otherwise maps to the same memory channel / bank)
+        pad = int(os.environ.get("OPB_Y_PAD", "0")) // 2
+        ybuf = torch.empty(M * N + pad, device=dev, dtype=torch.bfloat16)
+        y = ybuf[pad:pad + M * N].view(M, N)
         sc = torch.rand(8, device=dev)
         rps = (M + 7) // 8
 
