@@ -23,11 +23,14 @@
 // first read a whole phase later; a P fragment written by compiler VALU is read by an asm MFMA at least one slot later.
 #include "common.h"
 
+#ifndef W_ABL
+#define W_ABL 0        // timing ablations (tools/r5_w64_abl.sh; results invalid): 1 exp -> mul, 2 no exponential work, 4 no row maxima, 8 no fragment reads,
+#endif                 // 16 no LDS-DMA in the loop, 32 no QK MFMAs, 64 no PV MFMAs, 128 no epilogue loads / stores, 256 no Q loads
 #define W_KT 64
 #define W_ROWB 192
 #define W_TILE (W_KT * W_ROWB)           // 12 KiB
 #define W_QB 256
-#define W_SMEM (4 * W_TILE)              // K0 | K1 | V0 | V1
+#define W_SMEM (12 * W_TILE)             // K0 | K1 | V0 | V1 | two Q / output tiles per wave (this item's, the next / previous one's)
 #define W_LAG 8.0f                     // log2 of the largest probability value a lagging row maximum may produce
 #define WA_Q 96
 #define WA_K 144
@@ -94,45 +97,40 @@ template <bool ADD_Q>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                               float* __restrict__ LSE, int heads, int Lq, int Lk_all, float scale_log2e,
-                                                              float* __restrict__ /*unused*/, int /*unused*/) {
+                                                              float* __restrict__ /*unused*/, int n_bh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int qtile, bh;
-    xcd_group_map(qtile, bh);
+#ifdef W_STAMP
+    float* const LSE_stamp = LSE;      // diagnostic build: the LSE buffer carries the stamps instead (averages over a workgroup's items, in
+    LSE = nullptr;                     // the slot of its last one)
+    float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int n_it = 0;
+#endif
     const int Lk = Lk_all;
-    const int64_t key0 = 0;
-    const int b = bh / heads, g = bh - b * heads;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qtile * W_QB + wave * 64;
-    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
-    const bf16_t* Kb = Kt + ((int64_t)bh * Lk_all + key0) * 96;
-    const bf16_t* Vb = V + ((int64_t)bh * Lk_all + key0) * 96;
-
-    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\t" ::: W_CLOB_ALL);      // O^T = 0; the clobber list is what reserves a[0:239] for the asm text
-    int qi[2];
-    bool q_ok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        qi[j] = q0 + 32 * j + r;
-        q_ok[j] = qi[j] < Lq;
-        qi[j] = q_ok[j] ? qi[j] : Lq - 1;
-    }
-    // Q^T fragments: lane (r, h) holds Q[q0 + 32 j + r][16 ks + 8 h .. + 7]
-    {   // all twelve fragment loads in flight together, then the ACC writes
-        uint4 uq[12];
-#pragma unroll
-        for (int I = 0; I < 12; ++I) uq[I] = *reinterpret_cast<const uint4*>(Qb + (int64_t)qi[I / 6] * 96 + 16 * (I % 6) + 8 * h);
-        // Q is scaled by scale * log2(e) once, here: the scores leave the MFMA chain in log2 units and, with the accumulators started at
-        // -reference point, as the exponent itself -- no multiply-add per score in the loop (64 per lane and tile)
-        auto scl = [&](uint32_t u) { return pack_bf16x2(lo16_to_f32(u) * scale_log2e, hi16_to_f32(u) * scale_log2e); };
-#pragma unroll
-        for (int I = 0; I < 12; ++I) uq[I] = make_uint4(scl(uq[I].x), scl(uq[I].y), scl(uq[I].z), scl(uq[I].w));
-        w_for<0, 12>([&](auto I) { w_qput<WA_Q + 4 * I>(uq[I]); });
-    }
-
-    // LDS-DMA: waves 0, 1 move K tiles, waves 2, 3 V tiles, six 1-KiB pieces each (layout and swizzle as in attention.hip)
     const bool is_v = wave >= 2;
-    const char* src_bh = reinterpret_cast<const char*>(is_v ? Vb : Kb);
+    // Work items = (256-query tile, batch x head) pairs, taken v = blockIdx.x, + gridDim.x, ... by a grid of at most one workgroup per CU
+    // (attn_fwd_w64_launch): a workgroup that has a next item requests its Q tile and first K / V tiles BEFORE the epilogue of the
+    // current one, so that memory latency runs under the epilogue instead of in front of the next prologue, and the finished output
+    // tile leaves LDS only after the next item's operands have landed.  Item -> (tile, group): xcd_group_map's rule on the virtual
+    // index (the grid is a multiple of 8 whenever a workgroup takes more than one item, so v keeps its workgroup's XCD).
+    const int nqt = (Lq + W_QB - 1) / W_QB, n_items = nqt * n_bh;
+    auto item_of = [&](int v, int& qt, int& grp) {
+        if ((n_bh & 7) == 0) {
+            const int xcd = v & 7, slot = v >> 3, gq = slot / nqt;
+            grp = gq * 8 + xcd;
+            qt = slot - gq * nqt;
+        } else {
+            grp = v / nqt;
+            qt = v - grp * nqt;
+        }
+    };
+    int v_item = blockIdx.x, qtile, bh;
+    item_of(v_item, qtile, bh);
+    int q0 = qtile * W_QB + wave * 64;
+    const bf16_t* Qb = Q + (int64_t)bh * Lq * 96;
+    // LDS-DMA: waves 0, 1 move K tiles, waves 2, 3 V tiles, six 1-KiB pieces each (layout and swizzle as in attention.hip)
+    const char* src_bh = reinterpret_cast<const char*>((is_v ? V : Kt) + (int64_t)bh * Lk_all * 96);
     auto piece_off = [&](int i, int ln, int last_row) -> uint32_t {
         const int p = 64 * (6 * (wave & 1) + i) + ln;
         int row = p / 12, c = p - row * 12;
@@ -156,9 +154,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     const int nkt = (Lk + W_KT - 1) / W_KT;
     const bool ragged = (Lk % W_KT) != 0;
     auto tile_key0 = [&](int tile) { return ragged ? (tile == 0 ? (nkt - 1) * W_KT : (tile - 1) * W_KT) : tile * W_KT; };
-    auto dma = [&](int tile) {               // this wave's six pieces of K / V tile `tile` into buffer tile & 1
+    auto dma = [&](const char* kv_bh, int tile) {               // this wave's six pieces of K / V tile `tile` into buffer tile & 1
         const int k0 = tile_key0(tile);
-        const char* t_base = src_bh + (int64_t)k0 * W_ROWB;
+        const char* t_base = kv_bh + (int64_t)k0 * W_ROWB;
         const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_a + (tile & 1) * W_TILE);
         if (k0 + W_KT <= Lk) {
 #pragma unroll
@@ -221,16 +219,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     wf32x2 e_p[2];                     // in-flight pair state (two pairs are in flight in the pipelined phases)
     auto ex_b0 = [&](f32x16 (&s)[2][2], auto J, auto E, auto K) {
         constexpr int j = J, e = E, k = K, u = e / 4, jj = e % 4, kb = u / 2, sh = u % 2;
-        e_p[k][0] = __builtin_amdgcn_exp2f(s[j][kb][8 * sh + 2 * jj]);
+        if constexpr (W_ABL & 2) return;
+        e_p[k][0] = (W_ABL & 1) ? s[j][kb][8 * sh + 2 * jj] * 1.0001f : __builtin_amdgcn_exp2f(s[j][kb][8 * sh + 2 * jj]);
         asm volatile("" : "+v"(e_p[k][0]));
     };
     auto ex_b1 = [&](f32x16 (&s)[2][2], auto J, auto E, auto K) {
         constexpr int j = J, e = E, k = K, u = e / 4, jj = e % 4, kb = u / 2, sh = u % 2;
-        e_p[k][1] = __builtin_amdgcn_exp2f(s[j][kb][8 * sh + 2 * jj + 1]);
+        if constexpr (W_ABL & 2) return;
+        e_p[k][1] = (W_ABL & 1) ? s[j][kb][8 * sh + 2 * jj + 1] * 1.0001f : __builtin_amdgcn_exp2f(s[j][kb][8 * sh + 2 * jj + 1]);
         asm volatile("" : "+v"(e_p[k][1]));
     };
     auto ex_c = [&](bf16x8 (&pf)[2][4], auto J, auto E, auto K, wf32x2& ps) {             // row sum, pack; fourth word closes the fragment
         constexpr int j = J, e = E, k = K, u = e / 4, jj = e % 4;
+        if constexpr (W_ABL & 2) return;
         ps[0] += e_p[k][0];
         ps[1] += e_p[k][1];
         pw[j][u][jj] = pack_bf16x2(e_p[k][0], e_p[k][1]);
@@ -257,21 +258,104 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         }
     };
 
-    // ---- prologue: K(0), K(1), V(0) in; S(0), its softmax; K(1) fragments; K(2) on its way ---------------------------------
-    dma(0);
-    if (!is_v && nkt > 1) dma(1);
+    // ---- prologue: K(0), K(1), V(0) and this wave's Q tile on their way together; S(0), its softmax; K(1) fragments; K(2) ------
+    // The wave's 64 query rows go through LDS (its own 12-KiB region behind the K / V ring, K's row image): whole 192-byte rows by
+    // LDS-DMA instead of twelve 32-byte-per-row register loads, one memory latency for Q, K and V together, and the raw rows stay
+    // there for the epilogue's + q and as the staging area of the output tile (stored as whole rows as well).  Measured with the
+    // ablation builds (profiles/r5_attn_w64_ablations.txt): the register loads and the per-lane 8-byte loads / stores of the epilogue
+    // were 24 % of the kernel at Lk = 1568.
+    auto qo_region = [&](int p) -> uint32_t { return __builtin_amdgcn_readfirstlane(smem_a + (4 + 2 * wave + p) * W_TILE); };
+    auto qo_slot = [&](int ln, int i, int& row, int& chunk) {      // 16-byte slot 64 i + lane of a region holds chunk `chunk` of tile row `row`
+        const int p = 64 * i + ln;
+        row = p / 12;
+        chunk = p - row * 12 - ((row >> 2) & 3);
+        chunk = chunk < 0 ? chunk + 12 : chunk;
+    };
+    auto issue_loads = [&](const char* kv_bh, const bf16_t* q_bh, int q0_, uint32_t qo) {      // an item's first K / V tiles and Q tile
+        dma(kv_bh, 0);
+        if (!is_v && nkt > 1) dma(kv_bh, 1);
+        int ln = lane;                  // (opaque: the slot arithmetic is recomputed where it is used, not kept in registers across the key loop)
+        asm volatile("" : "+v"(ln));
+        if (!(W_ABL & 256)) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                int row, chunk;
+                qo_slot(ln, i, row, chunk);
+                row = q0_ + row < Lq ? q0_ + row : Lq - 1;          // rows past Lq re-read the last one (never stored)
+                dma1(reinterpret_cast<const char*>(q_bh), (uint32_t)(row * W_ROWB + chunk * 16), qo + 1024 * i);
+            }
+        }
+    };
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x2* lds_u2p;
+    typedef const __attribute__((address_space(3))) u32x4* lds_u4p;
+    auto store_rows = [&](uint32_t qo, char* obase, int q0_) {       // a finished 64 x 96 tile: LDS region -> whole rows of the output
+        const int C = heads * 96;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        u32x4 u[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) u[i] = *(lds_u4p)(uintptr_t)(qo + 1024 * i + 16 * ln);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            int row, chunk;
+            qo_slot(ln, i, row, chunk);
+            if (q0_ + row < Lq && !(W_ABL & 128)) *reinterpret_cast<u32x4*>(obase + (int64_t)row * C * 2 + chunk * 16) = u[i];
+        }
+    };
+    int par = 0;
+    char* pend_obase = nullptr;       // the previous item's output tile still waits in region par ^ 1
+    int pend_q0 = 0;
+    issue_loads(src_bh, Qb, q0, qo_region(0));
+  for (;;) {
+    const uint32_t qo_a = qo_region(par);
+    l_run[1] = 0.f;
+#ifdef W_STAMP
+    uint64_t t_entry;
+    W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory"); W_SB;
+#endif
+    int Lk_it = Lk;                   // opaque per item: the 64 lane masks of the ragged tile are not worth 128 scalar registers across the loop
+    asm volatile("" : "+s"(Lk_it));
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\t" ::: W_CLOB_ALL);      // O^T = 0; the clobber list is what reserves a[0:239] for the asm text
+    int qi[2];
+    bool q_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qi[j] = q0 + 32 * j + r;
+        q_ok[j] = qi[j] < Lq;
+        qi[j] = q_ok[j] ? qi[j] : Lq - 1;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (pend_obase) store_rows(qo_region(par ^ 1), pend_obase, pend_q0);
+#ifdef W_STAMP
+    uint64_t t_landed;
+    W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_landed) :: "memory"); W_SB;
+#endif
     f32x16 sa[2][2], sb[2][2];
     bf16x8 pa[2][4], pb[2][4];
-    w_for<0, 12>([&](auto I) { k_read(I, 0u); });
+    w_for<0, 12>([&](auto I) { k_read(I, 0u); });          // (asm, into ACC registers: in flight under the Q arithmetic below)
+    {   // Q^T fragments: lane (r, h) holds Q[q0 + 32 j + r][16 ks + 8 h .. + 7], read like a K fragment (query block j = key block kb)
+        u32x4 uq[12];
+#pragma unroll
+        for (int I = 0; I < 12; ++I) {
+            const int j = I / 6, ks = I % 6;
+            const uint32_t a = (ks < 4 ? ka0 + 32 * ks : ks == 4 ? ka4 : ka5) - smem_a + qo_a + 32 * W_ROWB * j;
+            uq[I] = *(lds_u4p)(uintptr_t)a;
+        }
+        // Q is scaled by scale * log2(e) once, here: the scores leave the MFMA chain in log2 units and, with the accumulators started at
+        // -reference point, as the exponent itself -- no multiply-add per score in the loop (64 per lane and tile)
+        auto scl = [&](uint32_t u) { return pack_bf16x2(lo16_to_f32(u) * scale_log2e, hi16_to_f32(u) * scale_log2e); };
+        w_for<0, 12>([&](auto I) { w_qput<WA_Q + 4 * I>(make_uint4(scl(uq[I][0]), scl(uq[I][1]), scl(uq[I][2]), scl(uq[I][3]))); });
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
     w_for<0, 24>([&](auto I) { qk(I, sa, std::true_type{}); });      // S(0) from zero: its reference point is not known yet
     W_SB;
     if (nkt > 1) w_for<0, 12>([&](auto I) { k_read(I, (uint32_t)W_TILE); });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                    // every wave has read K buffers 0 and 1
-    if (!is_v && nkt > 2) dma(2);
+    if (!is_v && nkt > 2) dma(src_bh, 2);
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));      // S(0) has left the matrix pipe
     {
         if (ragged) {                           // tile 0 is the ragged tail: keys >= Lk get -inf
@@ -282,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = (nkt - 1) * W_KT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        sa[j][kb][i] = key < Lk ? sa[j][kb][i] : -INFINITY;
+                        sa[j][kb][i] = key < Lk_it ? sa[j][kb][i] : -INFINITY;
                     }
         }
         float mx[2];
@@ -308,7 +392,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     // ---- one key tile: P(t) complete in pc; S(t+1) is produced in phase 1 and turned into P(t+1) (pn) in phase 2 -------------
 #ifdef W_STAMP
     uint64_t tacc[4] = {0, 0, 0, 0}, tprev;
-    float dbg_moved = 0.f, dbg_mx = 0.f;
 #define W_T0() { W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory"); W_SB; }
 #define W_T(N) { uint64_t tn_; W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); W_SB; tacc[N] += tn_ - tprev; tprev = tn_; }
 #else
@@ -342,9 +425,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         if constexpr (NEXT) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // K(t+1) fragments (requested a phase ago)
             w_for<0, 24>([&](auto I) {
-                qk(I, sn, std::false_type{});
-                if constexpr (I < 12) v_read(I, vb_off);
-                else if constexpr ((I & 1) == 0) dma_piece(IC<(I - 12) / 2>{});
+                if constexpr (!(W_ABL & 32)) qk(I, sn, std::false_type{});
+                if constexpr (I < 12) { if constexpr (!(W_ABL & 8)) v_read(I, vb_off); }
+                else if constexpr ((I & 1) == 0 && !(W_ABL & 16)) dma_piece(IC<(I - 12) / 2>{});
                 // GENERATED PHASE1 BEGIN (tools/gen_w64_slots.py)
                 if constexpr (I == 0) { ex_b0(so, J1{}, IC<0>{}, IC<0>{}); ex_b1(so, J1{}, IC<0>{}, IC<0>{}); }
                 if constexpr (I == 1) { ex_b0(so, J1{}, IC<1>{}, IC<1>{}); ex_b1(so, J1{}, IC<1>{}, IC<1>{}); }
@@ -388,9 +471,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         wf32x2 psB[2] = {{0.f, 0.f}, {0.f, 0.f}};
         float mq[2][4];
         w_for<0, 24>([&](auto I) {
-            pv(I, pc);
-            if constexpr (KRD && I < 12) k_read(I, kb_off);
-            if constexpr (NEXT && I >= 2 && I < 6) {
+            if constexpr (!(W_ABL & 64)) pv(I, pc);
+            if constexpr (KRD && I < 12 && !(W_ABL & 8)) k_read(I, kb_off);
+            if constexpr (NEXT && I >= 2 && I < 6 && (W_ABL & 4)) {
+                if constexpr (I == 2) { mq[0][0] = mq[0][1] = mq[0][2] = mq[0][3] = mq[1][0] = mq[1][1] = mq[1][2] = mq[1][3] = 0.f; }
+            }
+            if constexpr (NEXT && I >= 2 && I < 6 && !(W_ABL & 4)) {
                 // row maxima, four independent chains per query block, one quarter of the registers per slot.  (Not in slots 0, 1:
                 // the last QK MFMAs of phase 1 are asm, nothing pads their results; two PV MFMAs later they have landed.)
 #pragma unroll
@@ -459,10 +545,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
             l_run[0] = l_run[0] * alpha[0] + psB[0][0] + psB[0][1];
             l_run[1] *= alpha[1];
             W_T(2)
-#ifdef W_STAMP
-            if (moved) dbg_moved += 1.f;
-            dbg_mx = alpha[0];
-#endif
 #ifdef W_NORESCALE
             if (false) {
 #else
@@ -476,6 +558,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
         W_T(3)
         W_SB;
     };
+#ifdef W_STAMP
+    uint64_t t_loop0;
+    W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop0) :: "memory"); W_SB;
+#endif
     {
         using T_ = std::true_type;
         using F_ = std::false_type;
@@ -499,51 +585,111 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(const bf16_t* __re
     }
 
 #ifdef W_STAMP
-    if (LSE && lane == 0) {       // diagnostic build: cycles per tile in (wait + barrier, phase 1, phase 2, rescale + rest), one row per wave
-        for (int i = 0; i < 4; ++i) LSE[(int64_t)bh * Lq + qtile * W_QB + wave * 8 + i] = (float)tacc[i] / nkt;
-        LSE[(int64_t)bh * Lq + qtile * W_QB + wave * 8 + 4] = dbg_moved;
-        LSE[(int64_t)bh * Lq + qtile * W_QB + wave * 8 + 5] = dbg_mx;
-        LSE[(int64_t)bh * Lq + qtile * W_QB + wave * 8 + 6] = m_run[0];
-        LSE[(int64_t)bh * Lq + qtile * W_QB + wave * 8 + 7] = l_run[0];
-        return;
-    }
+    uint64_t t_loop1;
+    W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_loop1) :: "memory"); W_SB;
 #endif
-    // ---- epilogue: normalise, + q residual, store [b][q][g*96 + d] -------------------------------
+    // ---- the next item's first loads go out here: every wave has left the key loop (barrier: the K / V ring is free), and the
+    // epilogue below runs under their latency ----------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_barrier();
+    const int v_next = v_item + (int)gridDim.x;
+    const bool has_next = v_next < n_items;
+    int n_qtile = 0, n_bhh = 0, n_q0 = 0;
+    const bf16_t* n_Qb = nullptr;
+    const char* n_src = nullptr;
+    if (has_next) {
+        item_of(v_next, n_qtile, n_bhh);
+        n_q0 = n_qtile * W_QB + wave * 64;
+        n_Qb = Q + (int64_t)n_bhh * Lq * 96;
+        n_src = reinterpret_cast<const char*>((is_v ? V : Kt) + (int64_t)n_bhh * Lk_all * 96);
+        issue_loads(n_src, n_Qb, n_q0, qo_region(par ^ 1));
+    }
+    // ---- epilogue: normalise, + q residual (the raw rows are still in this wave's LDS region), the 16-bit tile back into the same
+    // slots, then whole rows out: store [b][q][g*96 + d] ------------------------------------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int rot = (r >> 2) & 3;
+    lds_u2p slot[12];                 // chunk 4 db + i4 of tile row r (query block 0; block 1 is 32 rows further), half h
+    w_for<0, 12>([&](auto I) {
+        int pc = I + rot;
+        pc = pc >= 12 ? pc - 12 : pc;
+        slot[I] = (lds_u2p)(uintptr_t)(qo_a + r * W_ROWB + pc * 16 + 8 * h);
+    });
+    u32x2 qres[2][12];                // all 24 residual reads go out before the first slot is overwritten
+    if (ADD_Q && !(W_ABL & 128)) {
+        w_for<0, 24>([&](auto I) { qres[I / 12][I % 12] = *(lds_u2p)((__attribute__((address_space(3))) char*)slot[I % 12] + 32 * W_ROWB * (I / 12)); });
+    }
     w_for<0, 2>([&](auto J) {
         constexpr int j = J;
         const float l_tot = l_run[j] + __shfl_xor(l_run[j], 32, 64);
         const float inv = 1.0f / l_tot;
         if (LSE && q_ok[j] && h == 0) LSE[(int64_t)bh * Lq + qi[j]] = m_run[j] + __builtin_amdgcn_logf(l_tot);  // log2 domain
-        const int C = heads * 96;
-        bf16_t* orow = O + ((int64_t)b * Lq + qi[j]) * C + g * 96;
-        const bf16_t* qrow = Qb + (int64_t)qi[j] * 96;
         w_for<0, 12>([&](auto I) {
-            constexpr int db = I / 4, i4 = I % 4;
+            constexpr int db = I / 4, i4 = I % 4;                 // d = 32 db + 8 i4 + 4 h .. + 3: half h of 16-byte chunk 4 db + i4 = I
             float4 v;
             w_oget4<16 * (3 * j + db) + 4 * i4>(v);
-            const int d = 32 * db + 8 * i4 + 4 * h;
             v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
-            if (ADD_Q) {
-                const float4 qq = load4(qrow + d);
-                v.x += qq.x; v.y += qq.y; v.z += qq.z; v.w += qq.w;
+            if (ADD_Q && !(W_ABL & 128)) {
+                const u32x2 u = qres[j][I];
+                v.x += lo16_to_f32(u[0]); v.y += hi16_to_f32(u[0]); v.z += lo16_to_f32(u[1]); v.w += hi16_to_f32(u[1]);
             }
-            if (q_ok[j]) store4(orow + d, v);
+            u32x2 o;
+            o[0] = pack_bf16x2(v.x, v.y);
+            o[1] = pack_bf16x2(v.z, v.w);
+            *(lds_u2p)((__attribute__((address_space(3))) char*)slot[I] + 32 * W_ROWB * j) = o;
         });
     });
+    {
+        const int b = bh / heads, g = bh - b * heads;
+        char* const obase = reinterpret_cast<char*>(O) + (((int64_t)b * Lq + q0) * (heads * 96) + g * 96) * 2;
+        if (!has_next) {
+            store_rows(qo_a, obase, q0);
+        } else {                  // rows go out at the top of the next item, behind its operands
+            pend_obase = obase;
+            pend_q0 = q0;
+        }
+    }
+#ifdef W_STAMP
+    uint64_t t_end;
+    W_SB; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory"); W_SB;
+    for (int i = 0; i < 4; ++i) sacc[i] += (float)tacc[i] / nkt;
+    sacc[4] += (float)(t_landed - t_entry);
+    sacc[5] += (float)(t_loop0 - t_landed);
+    sacc[6] += (float)(t_end - t_loop1);
+    sacc[7] += (float)(t_end - t_entry);
+    ++n_it;
+    if (!has_next && LSE_stamp && lane == 0) {   // cycles per tile in (wait + barrier, phase 1, phase 2, rescale + rest), then per item:
+        // (top .. operands landed, rest of the prologue, key loop end .. epilogue end, all); one row of 8 per wave
+        float* dst = LSE_stamp + (int64_t)bh * Lq + qtile * W_QB + wave * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = sacc[i] / n_it;
+    }
+#endif
+    if (!has_next) break;
+    v_item = v_next; qtile = n_qtile; bh = n_bhh; q0 = n_q0; Qb = n_Qb; src_bh = n_src;
+    par ^= 1;
+  }
 }
 
-int attn_fwd_w64_prepare() { return MVIT_OK; }      // 48 KiB of dynamic LDS: no attribute needed
+int attn_fwd_w64_prepare() {      // 144 KiB of dynamic LDS
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_w64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_w64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM) != hipSuccess)
+        return MVIT_ELAUNCH;
+    return MVIT_OK;
+}
 
 // launcher used by mvit_attention_fwd (attention.hip) when this form is selected
 int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* out, float* lse, int B, int heads, int Lq, int Lk,
                         float scale_log2e, int add_q, hipStream_t st) {
-    dim3 grid((Lq + W_QB - 1) / W_QB, B * heads);
+    const int n_bh = B * heads, n_items = ((Lq + W_QB - 1) / W_QB) * n_bh;
+    static DevInts ncu_tab;
+    int n_wg = dev_cu_count(ncu_tab) & ~7;              // one workgroup per CU (512 registers per lane, 144 KiB of LDS); a multiple of 8: see item_of
+    static const char* env = getenv("MVIT_ATT_W64_WGS");       // A/B runs: 0 = one workgroup per item (no prefetch across items)
+    if (env) n_wg = atoi(env) > 0 ? (atoi(env) & ~7) : n_items;
+    if (n_wg <= 0 || n_wg > n_items) n_wg = n_items;
+    dim3 grid(n_wg);
     if (add_q)
         hipLaunchKernelGGL((attn_fwd_w64_kernel<true>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
-                           lse, heads, Lq, Lk, scale_log2e, nullptr, 0);
+                           lse, heads, Lq, Lk, scale_log2e, nullptr, n_bh);
     else
         hipLaunchKernelGGL((attn_fwd_w64_kernel<false>), grid, dim3(256), W_SMEM, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out,
-                           lse, heads, Lq, Lk, scale_log2e, nullptr, 0);
+                           lse, heads, Lq, Lk, scale_log2e, nullptr, n_bh);
     return MVIT_OK;
 }

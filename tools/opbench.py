@@ -112,11 +112,11 @@ def main():
             lse = torch.zeros(B * h * Lq, device=dev)
             _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5, 1,
                                             _hip.BF16, st))
-            t8 = lse.view(B * h, Lq)[:, :(Lq // 256) * 256].reshape(B * h, Lq // 256, 256)[..., :32].reshape(B * h, Lq // 256, 4, 8).float()
-            print("w64 debug (rescales per wave, last alpha, m_run, l_run):", [round(x, 3) for x in t8[..., 4:].mean(dim=(0, 1, 2)).tolist()], "first wave:", t8[0, 0, 0].tolist())
-            t = t8[..., :4]
-            print("w64 cycles per tile (wait+barrier, phase 1, phase 2, rescale+rest):", [round(x, 1) for x in t.mean(dim=(0, 1, 2)).tolist()],
-                  "sum", round(t.mean(dim=(0, 1, 2)).sum().item(), 1))
+            t8 = lse.view(B * h, Lq)[:, :(Lq // 256) * 256].reshape(B * h, Lq // 256, 256)[..., :32].reshape(-1, 8).float()
+            t8 = t8[t8[:, 7] > 0]            # one row per wave of every workgroup's LAST item (averages over its items)
+            print("w64 cycles per item (top .. operands landed, rest of the prologue, key loop end .. epilogue end, all):", [round(x, 1) for x in t8[:, 4:].mean(dim=0).tolist()], "rows", t8.shape[0])
+            print("w64 cycles per tile (wait+barrier, phase 1, phase 2, rescale+rest):", [round(x, 1) for x in t8[:, :4].mean(dim=0).tolist()],
+                  "sum", round(t8[:, :4].mean(dim=0).sum().item(), 1))
         if os.environ.get("ATT_STAMP"):      # library built with -DATT_STAMP: per-phase cycle averages land in the LSE buffer
             lse = torch.zeros(B * h * Lq, device=dev)
             _hip.check(L.mvit_attention_fwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), B, h, Lq, Lk, 96 ** -0.5, 1,
