@@ -11,6 +11,9 @@
 
 #include "common.h"
 
+#ifndef BWD_ABL
+#define BWD_ABL 0         // timing ablations of the dQ pass (results invalid): 1 no dO re-read in the epilogue, 2 no dQ stores, 4 no register operand loads
+#endif
 #define B_T 64            // streamed rows per tile
 #define B_ROWB 192
 typedef __attribute__((address_space(3))) bf16x4 lds_b4;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     bf16x8 qf[6], dof[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks) {
+        if (BWD_ABL & 4) { for (int e = 0; e < 8; ++e) { qf[ks][e] = (short)(lane + e); dof[ks][e] = (short)(lane * 3 + e); } continue; }
         qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qi * 96 + 16 * ks + 8 * h);
         dof[ks] = *reinterpret_cast<const bf16x8*>(dOrow + 16 * ks + 8 * h);
     }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const bf16_t* Orow = O + ((int64_t)b * Lq + qi) * C + g * 96;
         bf16x8 of[6];
 #pragma unroll
-        for (int ks = 0; ks < 6; ++ks) of[ks] = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * h);
+        for (int ks = 0; ks < 6; ++ks) { if (BWD_ABL & 4) { of[ks] = dof[ks]; continue; } of[ks] = *reinterpret_cast<const bf16x8*>(Orow + 16 * ks + 8 * h); }
         float sp = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks)
@@ -419,21 +423,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #undef DQ_DQ
 #undef TRQ
     }
-    if (q_ok) {
+    {   // dQ rows.  Lane (r, h) holds elements 4h .. 4h+3 of every 8-element chunk of its query's row (the accumulator layout) and the
+        // whole chunks 2 ks + h of dO (the fragment layout): one v_permlane32_swap pair per k-step turns the dO registers into the
+        // halves this lane adds (the + q residual of the forward: dQ += dO; formerly twelve 8-byte reloads per lane), a second pair
+        // gives lane (r, 0) the whole chunk 2 ks and lane (r, 1) the whole chunk 2 ks + 1 of the result: six 16-byte stores.
         bf16_t* orow = dQ + ((int64_t)bh * Lq + qi) * 96;
 #pragma unroll
-        for (int db = 0; db < 3; ++db)
+        for (int ks = 0; ks < 6; ++ks) {
+            // dO halves: swap(word0, word2) -> (first word of my half of chunk 2 ks, of chunk 2 ks + 1); swap(word1, word3) -> second words
+            const uint4 dw = *reinterpret_cast<const uint4*>(&dof[ks]);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(dw.x, dw.z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(dw.y, dw.w, false, false);
+            uint32_t outw[2][2];
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int d = 32 * db + 8 * i4 + 4 * h;
-                float4 v = make_float4(dq[db][4 * i4] * scale, dq[db][4 * i4 + 1] * scale, dq[db][4 * i4 + 2] * scale,
-                                       dq[db][4 * i4 + 3] * scale);
-                if (ADD_Q) {
-                    const float4 dd = load4(dOrow + d);
-                    v.x += dd.x; v.y += dd.y; v.z += dd.z; v.w += dd.w;
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * ks + cc, db = c >> 2, i4 = c & 3;
+                float4 v = make_float4(dq[db][4 * i4] * scale, dq[db][4 * i4 + 1] * scale, dq[db][4 * i4 + 2] * scale, dq[db][4 * i4 + 3] * scale);
+                if (ADD_Q && !(BWD_ABL & 1)) {
+                    const uint32_t w0 = s0[cc], w1 = s1[cc];
+                    v.x += lo16_to_f32(w0); v.y += hi16_to_f32(w0); v.z += lo16_to_f32(w1); v.w += hi16_to_f32(w1);
                 }
-                store4(orow + d, v);
+                outw[cc][0] = pack_bf16x2(v.x, v.y);
+                outw[cc][1] = pack_bf16x2(v.z, v.w);
             }
+            // whole chunks: swap(P[2ks].w, P[2ks+1].w) -> (elements 0..3 half, elements 4..7 half) of the chunk this lane stores
+            const auto t0 = __builtin_amdgcn_permlane32_swap(outw[0][0], outw[1][0], false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(outw[0][1], outw[1][1], false, false);
+            const uint4 o = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            if (q_ok && (!(BWD_ABL & 2) || o.x == 0x12345u)) *reinterpret_cast<uint4*>(orow + 16 * ks + 8 * h) = o;
+        }
     }
 }
 
