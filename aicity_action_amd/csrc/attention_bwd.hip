@@ -12,7 +12,7 @@
 #include "common.h"
 
 #ifndef BWD_ABL
-#define BWD_ABL 0         // timing ablations of the dQ pass (results invalid): 1 no dO re-read in the epilogue, 2 no dQ stores, 4 no register operand loads
+#define BWD_ABL 0         // timing ablations of the dQ pass (results invalid): 1 no dO re-read in the epilogue, 2 no dQ stores, 4 no register operand loads, 8 dK/dV pass without its lse / delta reads
 #endif
 #define B_T 64            // streamed rows per tile
 #define B_ROWB 192
@@ -469,7 +469,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #define BK_IMG (B_T * B_ROWB)               // 12 KiB: one 64 x 96 rotation image
 #define BK_STAGEB (2 * BK_IMG + 1024)       // Q image | dO image | lse[64] | delta[64] | 2 x 256 B landing pads
 #define BK_LDS (BK_STAGES * BK_STAGEB)      // 75 KiB: two workgroups per CU
-template <bool SPLIT>
+// PRE (round 5): the query tiles are the pre-scaled 16-bit queries (Qs of the dQ pass / delta kernel), so Q . K^T is the exponent's
+// variable part itself.  The wave's K and V fragments are then NEGATED once and the two accumulators of a query block start at + lse / + delta
+// of their rows (the float4 reads from the stage land in the accumulator registers): the chains leave lse - S and delta - dP, P = exp2 of the
+// negated first (a source modifier) and dS = - P (delta - dP) (another): per 32 x 32 block 16 multiply-adds, 16 subtractions and the
+// zero-fill of 32 accumulator registers less.
+template <bool SPLIT, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kt,
                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                               const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -552,6 +557,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         // consume the register operands once: their vmcnt wait is paid here, not inside the loop
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+        if constexpr (PRE) {
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                uint4 a = *reinterpret_cast<const uint4*>(&kf[ks]), c = *reinterpret_cast<const uint4*>(&vf[ks]);
+                a.x ^= 0x80008000u; a.y ^= 0x80008000u; a.z ^= 0x80008000u; a.w ^= 0x80008000u;
+                c.x ^= 0x80008000u; c.y ^= 0x80008000u; c.z ^= 0x80008000u; c.w ^= 0x80008000u;
+                kf[ks] = *reinterpret_cast<const bf16x8*>(&a);
+                vf[ks] = *reinterpret_cast<const bf16x8*>(&c);
+            }
+        }
     }
     int roff[6];
 #pragma unroll
@@ -605,8 +620,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         auto block = [&](auto qb_tag) {
             constexpr int qb = decltype(qb_tag)::value;
             f32x16 s, dp;
+            if constexpr (PRE) {           // rows 32qb + 8g + 4h + 0..3 in registers 4g .. 4g+3
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+                for (int g = 0; g < 4; ++g) {
+                    float4 l4, d4;
+                    if (BWD_ABL & 8) { l4 = make_float4(20.f, 20.f, 20.f, 20.f); d4 = make_float4(0.f, 0.f, 0.f, 0.f); }     // (timing ablation: no lse / delta reads)
+                    else {
+                        l4 = *reinterpret_cast<const float4*>(sL + 32 * qb + 8 * g + 4 * h);
+                        d4 = *reinterpret_cast<const float4*>(sL + 64 + 32 * qb + 8 * g + 4 * h);
+                    }
+                    s[4 * g] = l4.x; s[4 * g + 1] = l4.y; s[4 * g + 2] = l4.z; s[4 * g + 3] = l4.w;
+                    dp[4 * g] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            }
             const char* qr = sQ + (32 * qb + r) * B_ROWB;
             const char* dr = sD + (32 * qb + r) * B_ROWB;
 #pragma unroll
@@ -620,6 +649,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float pv[8], dsv[8];
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(-s[8 * sh + e]);
+                        pv[e] = p;
+                        dsv[e] = p * -dp[8 * sh + e];
+                    }
+                } else
 #pragma unroll
                 for (int g4 = 0; g4 < 2; ++g4) {
                     // rows 32qb + 8*(2sh+g4) + 4h + 0..3
@@ -936,12 +973,15 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         MVIT_LAUNCH_CHECK();
         static DevFlags dkv_attr_done_tab; DevFlag dkv_attr_done = dev_flag(dkv_attr_done_tab);
         if (!dkv_attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS) != hipSuccess)
                 return MVIT_ELAUNCH;
             dkv_attr_done = true;
         }
         const int nz = dkv_splits(B, heads, Lq, Lk);
+        static const bool dkv_pre = !(getenv("MVIT_ATT_DKV_PRE") && atoi(getenv("MVIT_ATT_DKV_PRE")) == 0);      // A/B switch
         // pre-scaled queries: the scores come out of the MFMA in the exp2 domain (multiplier 1), and dK = scale * dS^T q =
         // (scale / (scale log2e)) * dS^T qs
         const bf16_t* q_kv = qs ? qs : (const bf16_t*)q;
@@ -951,6 +991,10 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             const int64_t nkv = (int64_t)B * heads * Lk * 96;
             float* dvf = dkf + (int64_t)nz * nkv;
             dim3 gk((Lk + 127) / 128, B * heads, nz);
+            if (qs && dkv_pre)
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
+                                   (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv);
+            else
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
                                (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv);
             MVIT_LAUNCH_CHECK();
@@ -960,6 +1004,10 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
             MVIT_LAUNCH_CHECK();
         } else {
             dim3 gk((Lk + 127) / 128, B * heads);
+            if (qs && dkv_pre)
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
+                                   (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale_kv, sl2_kv);
+            else
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
                                (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale_kv, sl2_kv);
             MVIT_LAUNCH_CHECK();
