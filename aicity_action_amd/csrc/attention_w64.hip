@@ -16,6 +16,10 @@
 //   phase 1:  S(t+1) = K(t+1) Q^T        beside  V^T(t) fragment reads, the second half of tile t's exponentials
 //   phase 2:  O^T += V^T(t) P(t)^T       beside  K(t+2) fragment reads, the row maxima of S(t+1), the first half of its exponentials
 // one s_barrier per tile; K tiles arrive by LDS-DMA three tiles ahead, V tiles one ahead, two buffers each.
+// Around the key loop (round 5; ablation builds showed a quarter of the kernel in an item's first loads and last stores):
+// a wave's 64 query rows arrive by LDS-DMA as whole rows in its own LDS region and stay there for the + q residual; the finished 16-bit output
+// tile goes back into the same slots and leaves as whole rows; the grid is persistent (at most one workgroup per CU, items v = blockIdx.x,
+// + gridDim.x, ...) and a workgroup requests its NEXT item's Q tile and first K / V tiles before the epilogue of the current one (two regions per wave).
 // Q is multiplied by scale * log2(e) once (and rounded to the 16-bit type again) and every score accumulator STARTS at minus the row's
 // reference point, so the scores leave the MFMA chain as the exponent itself: a pair of scores costs two v_exp, two adds and a pack.
 // Every MFMA is an asm statement followed by its share of the softmax arithmetic and a scheduling barrier, so the instruction
