@@ -389,6 +389,33 @@ def test_attention_64_query_kernel_rescale_paths_and_lse(hip_lib, Lq, Lk):
     assert bool((err <= bound).all()), "lse err %.3e (bound there %.3e)" % (err.max().item(), bound.flatten()[err.argmax()].item())
 
 
+@pytest.mark.parametrize("B,h,Lq,Lk", [(2, 8, 256 * 40, 200), (3, 1, 256 * 100 - 100, 130), (1, 8, 256 * 33 + 70, 64)])
+def test_attention_64_query_kernel_persistent_grid(hip_lib, B, h, Lq, Lk):
+    """More (256-query tile, batch x head) items than workgroups of the persistent grid of csrc/attention_w64.hip (one per CU): every
+    workgroup then takes several items -- the next item's Q / K / V loads are issued before the current epilogue, the finished output tile
+    waits in LDS and leaves behind the next item's operands, the two LDS regions of a wave alternate -- with batch x head a multiple of
+    8 (items grouped per XCD) and not (plain order), ragged last query tiles, ragged and exact key tiles.  Output and lse against torch."""
+    q = _rnd(B, h, Lq, 96, seed=41).to(torch.bfloat16)
+    k = _rnd(B, h, Lk, 96, seed=42).to(torch.bfloat16)
+    v = _rnd(B, h, Lk, 96, seed=43).to(torch.bfloat16)
+    scale = 96 ** -0.5
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    s = (qd.float() @ kd.float().transpose(-2, -1)) * scale
+    ref = (s.softmax(-1) @ vd.float() + qd.float()).transpose(1, 2).reshape(B, Lq, h * 96)
+    ref_lse = torch.logsumexp(s, -1) * 1.4426950408889634
+    out = torch.full((B, Lq, h * 96), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((B, h, Lq), float("nan"), dtype=torch.float32, device=DEV)
+    for _ in range(2):      # (second call: same result from a warm cache and a reused LDS state)
+        _hip.check(hip_lib.mvit_attention_fwd(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vd), _hip.ptr(out), _hip.ptr(lse), B, h, Lq, Lk, scale, 1,
+                                              _hip.BF16, _st()))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all()), "rows left unwritten"
+        err = (out.float() - ref).abs().max().item()
+        assert err <= 1e-2 * max(1.0, ref.abs().max().item()), "output err %.3e" % err
+        bound = 2e-3 + (s.abs().amax(-1) * 1.4426950408889634) * 2.0 ** -9
+        assert bool(((lse - ref_lse).abs() <= bound).all())
+
+
 @pytest.mark.parametrize("B,T,H,W,C", [(2, 2, 16, 16, 192), (1, 3, 7, 7, 384), (1, 2, 14, 14, 768), (1, 1, 5, 9, 96)])
 def test_maxpool_skip(hip_lib, B, T, H, W, C):
     x = _rnd(B, T * H * W, C, seed=22)
