@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libmvit_hip.so")   # override: tools/ ablation builds only
-LIB_PATH_F16 = os.path.join(_HERE, "lib", "libmvit_hip_f16.so")   # same sources, 16-bit activation type = IEEE half
+LIB_PATH_F16 = os.environ.get("MVIT_HIP_LIB_F16") or os.path.join(_HERE, "lib", "libmvit_hip_f16.so")   # same sources, 16-bit activation type = IEEE half
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1

@@ -95,6 +95,17 @@ __device__ __forceinline__ f32x2 lds_pair<bf16_t>(const char* p) {
     r.y = hi16_to_f32(u);
     return r;
 }
+// fp16 build, stride 1: keep the conversions as instructions of their own.  Left alone the compiler folds them into the taps as v_fma_mix_f32
+// (fewer instructions), which issue below the plain v_fmac_f32 rate on gfx950 like the other packed-encoding fp32 arithmetic: the stride-1
+// kernel ran 22 % behind the bf16 build inside the fp16 forward (profiles/r5_fwd_fp16_vs_bf16_per_kernel.txt); with explicit conversions 48.5 -> 45.0 us
+// at stage 3 alone, 187.6 -> 178 at block 0.  The stride-2 form has fewer taps per loaded value and is better off folded (37.3 vs 41.5 us):
+// profiles/r5_pool_f16_fma_mix_ab.txt.
+template <int S>
+__device__ __forceinline__ void unfold_conversions(f32x2& r) {
+#if defined(MVIT_HALF_IS_FP16) && !defined(MARCH_FMA_MIX)      // (MARCH_FMA_MIX: A/B builds of the folded form)
+    if constexpr (S == 1) asm volatile("" : "+v"(r.x), "+v"(r.y));
+#endif
+}
 template <>
 __device__ __forceinline__ f32x2 lds_pair<float>(const char* p) {
     return *reinterpret_cast<const f32x2*>(p);
@@ -273,7 +284,10 @@ __global__ __launch_bounds__(448) void pool_march_kernel(const TA* __restrict__ 
             f32x2 xin[P::IW];
             const char* rp = tile + (S * row + dy) * P::IW * 96 * ES;
 #pragma unroll
-            for (int ix = 0; ix < P::IW; ++ix) xin[ix] = lds_pair<TA>(rp + ix * 96 * ES);
+            for (int ix = 0; ix < P::IW; ++ix) {
+                xin[ix] = lds_pair<TA>(rp + ix * 96 * ES);
+                if constexpr (sizeof(TA) == 2) unfold_conversions<S>(xin[ix]);
+            }
 #pragma unroll
             for (int dt = 0; dt < 3; ++dt) {    // input frame f is tap dt of output frame f + 1 - dt -> set (f + 1 - dt) % 3
                 const int a = (ph + 4 - dt) % 3;
