@@ -14,7 +14,8 @@
 //     the current frame's arithmetic; halo cells outside the image are zeroed once and never written again;
 //   * three rolling accumulator sets (output frames f-1, f, f+1) with COMPILE-TIME names: the frame body is instantiated for
 //     the three phases f mod 3, nothing is copied when the window moves; each LDS value is read once per dy and used for 9
-//     taps, arithmetic in plain v_fma_f32 (v_fma_mix_f32 in the fp16 build: the compiler folds the unpack), the 27 weight
+//     taps, arithmetic in plain v_fma_f32 (fp16 build: the stride-2 form lets the compiler fold the conversions into v_fma_mix_f32, the
+//     stride-1 form keeps them apart -- unfold_conversions below), the 27 weight
 //     reads per input row stay LDS reads (common.h::lds_opaque -- laundering the generic pointer made them FLAT loads);
 //   * the LayerNorm of a finished frame runs IN REGISTERS: the 96 channels of a token are the 48 lanes of one wave; the sums
 //     of a frame's 7 tokens are folded into each other (wave_sum_rows: v_permlane32_swap, v_permlane16_swap, 4 DPP levels on two
