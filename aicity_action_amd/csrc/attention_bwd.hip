@@ -12,7 +12,7 @@
 #include "common.h"
 
 #ifndef BWD_ABL
-#define BWD_ABL 0         // timing ablations of the dQ pass (results invalid): 1 no dO re-read in the epilogue, 2 no dQ stores, 4 no register operand loads, 8 dK/dV pass without its lse / delta reads
+#define BWD_ABL 0         // timing ablations of the dQ pass (results invalid): 1 no dO re-read in the epilogue, 2 no dQ stores, 4 no register operand loads, 8 dK/dV pass without its lse / delta reads, 16 without its exponential arithmetic, 32 without fragment reads, 64 without MFMAs
 #endif
 #define B_T 64            // streamed rows per tile
 #define B_ROWB 192
@@ -584,12 +584,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int t_hi0 = (4 * h + (i16 >> 2) + 8) * B_ROWB + 16 * rh + 8 * (i16 & 1);
     const int t_lo2 = (4 * h + (i16 >> 2)) * B_ROWB + 16 * (8 + rl >= 12 ? rl - 4 : 8 + rl) + 8 * (i16 & 1);
     const int t_hi2 = (4 * h + (i16 >> 2) + 8) * B_ROWB + 16 * (8 + rh >= 12 ? rh - 4 : 8 + rh) + 8 * (i16 & 1);
-    auto trf = [&](const char* img, int s16, int db) {      // one transposed 8-element fragment: two 4x16 transposing reads
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(img + s16 * 16 * B_ROWB + (db == 2 ? t_lo2 : t_lo0 + 64 * db)));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(img + s16 * 16 * B_ROWB + (db == 2 ? t_hi2 : t_hi0 + 64 * db)));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-
     f32x16 dk[3], dv[3];
 #pragma unroll
     for (int db = 0; db < 3; ++db)
@@ -603,7 +597,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         __builtin_amdgcn_s_barrier();                                              // ... for every wave; stage-1's readers are done
         if (qt + 2 < qt_end) dma(qt + 2, stage == 0 ? 2 : stage - 1);
         const char* sQ = smem + stage * BK_STAGEB;
-        const char* sD = sQ + BK_IMG;
         const float* sL = reinterpret_cast<const float*>(sQ + 2 * BK_IMG);      // lse[64] | delta[64]
         if ((qt + 1) * B_T > Lq) {
             // last, partial tile: its invalid rows were filled from the last valid query (finite data); their lse is set to +inf
@@ -617,6 +610,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         // per 32-query block (one S / dP accumulator pair live: the kernel fits 2 waves per SIMD):
         //   S = Q . K^T and dP = dO . V^T (rows = queries in registers, column = this lane's key), P / dS in registers,
         //   then dV^T += dO^T . P and dK^T += Q^T . dS for the block's two 16-query k-steps
+        // LDS reads of the block are issued by hand THREE fragments ahead of the MFMA that consumes them (a ring of four fragment registers,
+        // counted lgkmcnt waits).  Left to the compiler every MFMA waited for a read issued one MFMA earlier (register pressure keeps its
+        // prefetch distance at one); the second wave of the SIMD covers most of that, so the gain is small: -1.6 % at stage 3, -1.9 % at
+        // Lk = 6272, -3 % in blocks 14 / 15, the query-split launches +1 %; train step 46.06 -> 45.84 ms (profiles/r5_attn_dkv_pipelined_reads_ab.txt).
+        const uint32_t sQa = smem_a + (uint32_t)(sQ - smem) + r * B_ROWB;          // row reads: + roff[ks] (+ 32 qb rows, + BK_IMG for dO)
+        const uint32_t sTa = smem_a + (uint32_t)(sQ - smem);                        // transposing reads: + t_lo0 / t_hi0 / t_lo2 / t_hi2
         auto block = [&](auto qb_tag) {
             constexpr int qb = decltype(qb_tag)::value;
             f32x16 s, dp;
@@ -636,19 +635,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
             }
-            const char* qr = sQ + (32 * qb + r) * B_ROWB;
-            const char* dr = sD + (32 * qb + r) * B_ROWB;
-#pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qr + roff[ks]);
-                const bf16x8 df = *reinterpret_cast<const bf16x8*>(dr + roff[ks]);
-                s = mfma16(qf, kf[ks], s);
-                dp = mfma16(df, vf[ks], dp);
-            }
+            bf16x8 fr[4];
+            // read i of phase A: k-step i / 2 of the Q image (even i: S chain) or of the dO image (odd i: dP chain)
+            auto rdA = [&](auto I) {
+                constexpr int i = decltype(I)::value, ks = i / 2;
+                if (BWD_ABL & 32) { if (i < 4) fr[i & 3] = kf[i & 3]; return; }          // (timing ablation: no fragment reads)
+                fr[i & 3] = b_rd128<32 * qb * B_ROWB + (i & 1) * BK_IMG>(sQa + roff[ks]);
+            };
+            auto mmA = [&](auto I, auto N) {
+                constexpr int i = decltype(I)::value, ks = i / 2;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[i & 3]) : "n"(decltype(N)::value));
+                if (BWD_ABL & 64) return;                     // (timing ablation: no MFMAs)
+                if constexpr (i & 1) dp = mfma16(fr[i & 3], vf[ks], dp);
+                else s = mfma16(fr[i & 3], kf[ks], s);
+            };
+#define DKV_IC(N) std::integral_constant<int, N>{}
+            rdA(DKV_IC(0)); rdA(DKV_IC(1)); rdA(DKV_IC(2));
+            rdA(DKV_IC(3)); mmA(DKV_IC(0), DKV_IC(3));
+            rdA(DKV_IC(4)); mmA(DKV_IC(1), DKV_IC(3));
+            rdA(DKV_IC(5)); mmA(DKV_IC(2), DKV_IC(3));
+            rdA(DKV_IC(6)); mmA(DKV_IC(3), DKV_IC(3));
+            rdA(DKV_IC(7)); mmA(DKV_IC(4), DKV_IC(3));
+            rdA(DKV_IC(8)); mmA(DKV_IC(5), DKV_IC(3));
+            rdA(DKV_IC(9)); mmA(DKV_IC(6), DKV_IC(3));
+            rdA(DKV_IC(10)); mmA(DKV_IC(7), DKV_IC(3));
+            rdA(DKV_IC(11)); mmA(DKV_IC(8), DKV_IC(3));
+            mmA(DKV_IC(9), DKV_IC(2));
+            mmA(DKV_IC(10), DKV_IC(1));
+            mmA(DKV_IC(11), DKV_IC(0));
+            // phase B fragment j: 16-query step sh = j / 6, d block db = (j / 2) % 3; even j: dO image (dV^T += dO^T P), odd j: Q image (dK^T += Q^T dS)
+            auto rdB = [&](auto J) {
+                constexpr int j = decltype(J)::value, sh = j / 6, db = (j / 2) % 3;
+                constexpr int off = (2 * qb + sh) * 16 * B_ROWB + ((j & 1) ? 0 : BK_IMG) + (db == 2 ? 0 : 64 * db);
+                if (BWD_ABL & 32) return;
+                const bf16x4 lo = b_tr16<off>(sTa + (db == 2 ? t_lo2 : t_lo0));
+                const bf16x4 hi = b_tr16<off>(sTa + (db == 2 ? t_hi2 : t_hi0));
+                fr[j & 3] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            // the first three transposed fragments do not depend on the exponentials: in flight under them
+            rdB(DKV_IC(0)); rdB(DKV_IC(1)); rdB(DKV_IC(2));
             bf16x8 pf[2], dsf[2];
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float pv[8], dsv[8];
+                if constexpr (PRE && (BWD_ABL & 16)) {        // (timing ablation: no exponentials / products / packing)
+                    pf[sh] = vf[sh]; dsf[sh] = kf[sh];
+                    asm volatile("" : "+v"(pf[sh]), "+v"(dsf[sh]), "+v"(s), "+v"(dp));
+                    continue;
+                }
                 if constexpr (PRE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -676,13 +710,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 pf[sh] = pack8(pv);
                 dsf[sh] = pack8(dsv);
             }
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-                for (int db = 0; db < 3; ++db) {
-                    dv[db] = mfma16(trf(sD, 2 * qb + sh, db), pf[sh], dv[db]);
-                    dk[db] = mfma16(trf(sQ, 2 * qb + sh, db), dsf[sh], dk[db]);
-                }
+            auto mmB = [&](auto J, auto N) {       // (each fragment is two reads: N counts reads)
+                constexpr int j = decltype(J)::value, sh = j / 6, db = (j / 2) % 3;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[j & 3]) : "n"(decltype(N)::value));
+                if (BWD_ABL & 64) return;
+                if constexpr (j & 1) dk[db] = mfma16(fr[j & 3], dsf[sh], dk[db]);
+                else dv[db] = mfma16(fr[j & 3], pf[sh], dv[db]);
+            };
+            rdB(DKV_IC(3)); mmB(DKV_IC(0), DKV_IC(6));
+            rdB(DKV_IC(4)); mmB(DKV_IC(1), DKV_IC(6));
+            rdB(DKV_IC(5)); mmB(DKV_IC(2), DKV_IC(6));
+            rdB(DKV_IC(6)); mmB(DKV_IC(3), DKV_IC(6));
+            rdB(DKV_IC(7)); mmB(DKV_IC(4), DKV_IC(6));
+            rdB(DKV_IC(8)); mmB(DKV_IC(5), DKV_IC(6));
+            rdB(DKV_IC(9)); mmB(DKV_IC(6), DKV_IC(6));
+            rdB(DKV_IC(10)); mmB(DKV_IC(7), DKV_IC(6));
+            rdB(DKV_IC(11)); mmB(DKV_IC(8), DKV_IC(6));
+            mmB(DKV_IC(9), DKV_IC(4));
+            mmB(DKV_IC(10), DKV_IC(2));
+            mmB(DKV_IC(11), DKV_IC(0));
+#undef DKV_IC
         };
         block(std::integral_constant<int, 0>{});
         block(std::integral_constant<int, 1>{});
@@ -986,30 +1033,21 @@ extern "C" int mvit_attention_bwd(const void* q, const void* k, const void* v, c
         // (scale / (scale log2e)) * dS^T qs
         const bf16_t* q_kv = qs ? qs : (const bf16_t*)q;
         const float sl2_kv = qs ? 1.0f : sl2, scale_kv = qs ? scale / sl2 : scale;
+        const bool pre_kv = qs && dkv_pre;
+        float* dkf = nz > 1 ? workspace + rows : nullptr;
+        const int64_t nkv = (int64_t)B * heads * Lk * 96;
+        float* dvf = nz > 1 ? dkf + (int64_t)nz * nkv : nullptr;
+        dim3 gk((Lk + 127) / 128, B * heads, nz > 1 ? nz : 1);
+#define DKV_LAUNCH(SP, PR) hipLaunchKernelGGL((attn_bwd_dkv_kernel<SP, PR>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v, \
+                                          (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv)
+        if (nz > 1) { if (pre_kv) DKV_LAUNCH(true, true); else DKV_LAUNCH(true, false); }
+        else { if (pre_kv) DKV_LAUNCH(false, true); else DKV_LAUNCH(false, false); }
+#undef DKV_LAUNCH
+        MVIT_LAUNCH_CHECK();
         if (nz > 1) {
-            float* dkf = workspace + rows;
-            const int64_t nkv = (int64_t)B * heads * Lk * 96;
-            float* dvf = dkf + (int64_t)nz * nkv;
-            dim3 gk((Lk + 127) / 128, B * heads, nz);
-            if (qs && dkv_pre)
-                hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
-                                   (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv);
-            else
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
-                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, dkf, dvf, heads, Lq, Lk, scale_kv, sl2_kv);
-            MVIT_LAUNCH_CHECK();
             int64_t cb = (nkv / 4 + 255) / 256;
             if (cb > 4096) cb = 4096;
             hipLaunchKernelGGL(attn_bwd_dkv_reduce_kernel, dim3((unsigned)cb), dim3(256), 0, skv, dkf, dvf, (bf16_t*)dk, (bf16_t*)dv, nkv / 4, nz);
-            MVIT_LAUNCH_CHECK();
-        } else {
-            dim3 gk((Lk + 127) / 128, B * heads);
-            if (qs && dkv_pre)
-                hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
-                                   (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale_kv, sl2_kv);
-            else
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), gk, dim3(256), BK_LDS, skv, q_kv, (const bf16_t*)k, (const bf16_t*)v,
-                               (const bf16_t*)dout, lse, workspace, (bf16_t*)dk, (bf16_t*)dv, nullptr, nullptr, heads, Lq, Lk, scale_kv, sl2_kv);
             MVIT_LAUNCH_CHECK();
         }
         if (skv != st && !side_join(ss, st)) return MVIT_ELAUNCH;
