@@ -663,10 +663,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             mmA(DKV_IC(9), DKV_IC(2));
             mmA(DKV_IC(10), DKV_IC(1));
             mmA(DKV_IC(11), DKV_IC(0));
-            // phase B fragment j: 16-query step sh = j / 6, d block db = (j / 2) % 3; even j: dO image (dV^T += dO^T P), odd j: Q image (dK^T += Q^T dS)
+            // phase B fragment j: group j / 3 = (16-query step sh, product): dV^T += dO^T P (dO image) for sh = 0, then dK^T += Q^T dS (Q image) for
+            // sh = 0, then the same for sh = 1; d block db = j % 3.  In this order only P of the first 16 queries has to exist before the first
+            // MFMA: dS of those queries, then P and dS of the other 16 are formed under the MFMAs of the groups in front of them.
             auto rdB = [&](auto J) {
-                constexpr int j = decltype(J)::value, sh = j / 6, db = (j / 2) % 3;
-                constexpr int off = (2 * qb + sh) * 16 * B_ROWB + ((j & 1) ? 0 : BK_IMG) + (db == 2 ? 0 : 64 * db);
+                constexpr int j = decltype(J)::value, sh = j / 6, db = j % 3;
+                constexpr bool is_k = (j / 3) & 1;
+                constexpr int off = (2 * qb + sh) * 16 * B_ROWB + (is_k ? 0 : BK_IMG) + (db == 2 ? 0 : 64 * db);
                 if (BWD_ABL & 32) return;
                 const bf16x4 lo = b_tr16<off>(sTa + (db == 2 ? t_lo2 : t_lo0));
                 const bf16x4 hi = b_tr16<off>(sTa + (db == 2 ? t_hi2 : t_hi0));
@@ -711,10 +714,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 dsf[sh] = pack8(dsv);
             }
             auto mmB = [&](auto J, auto N) {       // (each fragment is two reads: N counts reads)
-                constexpr int j = decltype(J)::value, sh = j / 6, db = (j / 2) % 3;
+                constexpr int j = decltype(J)::value, sh = j / 6, db = j % 3;
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fr[j & 3]) : "n"(decltype(N)::value));
                 if (BWD_ABL & 64) return;
-                if constexpr (j & 1) dk[db] = mfma16(fr[j & 3], dsf[sh], dk[db]);
+                if constexpr ((j / 3) & 1) dk[db] = mfma16(fr[j & 3], dsf[sh], dk[db]);
                 else dv[db] = mfma16(fr[j & 3], pf[sh], dv[db]);
             };
             rdB(DKV_IC(3)); mmB(DKV_IC(0), DKV_IC(6));
