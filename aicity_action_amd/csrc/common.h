@@ -188,6 +188,14 @@ static inline SideStream* side_stream_for_current_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream* s = &tab[dev];
     if (!s->side) {
+        // The side stream gets the LOWEST stream priority: what runs on it (weight gradients, the second of two side-by-side passes) fills
+        // the gaps of the caller's chain, which is the critical path (train step 44.63 -> 44.52 ms, profiles/r5_side_stream_priority_ab.txt).
+        // MVIT_SIDE_PRIO=0: default priority, 2: highest (A/B runs).
+        static const int prio_env = getenv("MVIT_SIDE_PRIO") ? atoi(getenv("MVIT_SIDE_PRIO")) : 1;
+        int least = 0, greatest = 0;
+        if (prio_env && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
+            if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_env == 1 ? least : greatest) != hipSuccess) { s->side = nullptr; return nullptr; }
+        } else
         if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) { s->side = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess)
