@@ -188,10 +188,11 @@ static inline SideStream* side_stream_for_current_device() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream* s = &tab[dev];
     if (!s->side) {
-        // The side stream gets the LOWEST stream priority: what runs on it (weight gradients, the second of two side-by-side passes) fills
-        // the gaps of the caller's chain, which is the critical path (train step 44.63 -> 44.52 ms, profiles/r5_side_stream_priority_ab.txt).
-        // MVIT_SIDE_PRIO=0: default priority, 2: highest (A/B runs).
-        static const int prio_env = getenv("MVIT_SIDE_PRIO") ? atoi(getenv("MVIT_SIDE_PRIO")) : 1;
+        // MVIT_SIDE_PRIO (probe; default 0 = plain stream): 1 = lowest stream priority for the side stream, 2 = highest.  Lowest bought 0.1 ms of the
+        // train step on one box and nothing on another -- and a process that had created the prioritised stream ran the three sub-batch
+        // streams of the inference forward at 577 instead of 728 clips/s afterwards (the stream -> hardware queue assignment changes:
+        // profiles/r5_side_stream_priority_ab.txt).  Not adopted.
+        static const int prio_env = getenv("MVIT_SIDE_PRIO") ? atoi(getenv("MVIT_SIDE_PRIO")) : 0;
         int least = 0, greatest = 0;
         if (prio_env && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) {
             if (hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, prio_env == 1 ? least : greatest) != hipSuccess) { s->side = nullptr; return nullptr; }
