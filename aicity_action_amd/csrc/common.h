@@ -219,8 +219,7 @@ static inline bool side_join(SideStream* s, hipStream_t st) {
 #include <atomic>
 constexpr int MVIT_MAX_DEVS = 64;
 struct DevFlag {
-    std::atomic<bool>* slot;
-    bool scratch = false;
+    std::atomic<bool>* slot;          // nullptr = the uncached scratch case (reads false, writes dropped)
     operator bool() const { return slot ? slot->load(std::memory_order_acquire) : false; }
     DevFlag& operator=(bool v) { if (slot) slot->store(v, std::memory_order_release); return *this; }
 };

@@ -86,7 +86,8 @@ __device__ __forceinline__ void pp_dma(const char* base, uint32_t off, uint32_t 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #if PP_ABL & 8
 __device__ float g_pp_stamps[256 * 4];
-extern "C" int mvit_debug_pp_stamps(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(float) * 256 * 4) == hipSuccess ? 0 : -3; }
+/* ablation builds only (tools/opbench.py); not part of the C-ABI */
+extern "C" __attribute__((visibility("default"))) int mvit_debug_pp_stamps(float* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_stamps), sizeof(float) * 256 * 4) == hipSuccess ? 0 : -3; }
 #endif
 
 struct PPCur {          // DMA cursor: source of one K-tile

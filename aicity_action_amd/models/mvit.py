@@ -162,6 +162,11 @@ class MViT(nn.Module):
         self.head = _Head(geoms[-1].dim_out, self.num_classes)
         self.apply(self._init_weights)                               # :1119
         self._bf16_cache = {}
+        # error-budget instrument (tests/test_hip_model.py::test_fp16_error_budget_per_kernel_family, tools/error_budget.py): op families of
+        # the 16-bit inference forward that run on the exact-fp32 kernels instead (inputs widened, outputs rounded back to the 16-bit
+        # type where the next kernel reads 16 bit), ONE family at a time, to see what each contributes to the logit error.  Subset of
+        # {"stem", "qkv", "pool", "attention", "skip", "tail"}; empty = the product path.
+        self._exact_ops = frozenset()
 
     @staticmethod
     def _init_weights(m):                                            # :1126-1133
@@ -383,7 +388,7 @@ class MViT(nn.Module):
         outs = []
         self._substreams_active = True
         try:
-            for st_, part in zip(self._side_streams, torch.chunk(clip, ns, dim=0)):
+            for st_, part in zip(self._side_streams, torch.tensor_split(clip, ns, dim=0)):     # balanced: 7 clips on 3 streams = 3, 2, 2
                 st_.wait_stream(cur)
                 with torch.cuda.stream(st_):
                     outs.append(self._forward_hip(part.contiguous(), return_logits))
@@ -417,7 +422,7 @@ class MViT(nn.Module):
         pe = self.patch_embed.proj
         _hip.check(L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(pe.weight), _hip.ptr(pe.bias),
                                    _hip.ptr(self.pos_embed_spatial), _hip.ptr(self.pos_embed_temporal), _hip.ptr(x),
-                                   B, T, S, act, st), "stem")
+                                   B, T, S, _hip.F32 if "stem" in self._exact_ops else act, st), "stem")
         if taps is not None:
             taps["stem"] = x
         for g, blk in zip(self.geoms, self.blocks):
@@ -506,45 +511,64 @@ class MViT(nn.Module):
         M = B * N
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         at = blk.attn
+        ex = self._exact_ops if act != _hip.F32 else frozenset()
         # 1. U = LN1(x)                                                   attention.py:421
-        u = torch.empty(M, Cin, dtype=adt, device=dev)
-        _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
-                                        Cin, blk.norm1.eps, act, st), "norm1")
         # 2. fused qkv projection, kept token-major [B,N,3*Cout]          attention.py:230-236
-        qkv = self._linear(L, st, act, u, act, at.qkv, adt, M)
+        if "qkv" in ex:
+            u = torch.empty(M, Cin, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
+                                            Cin, blk.norm1.eps, _hip.F32, st), "norm1")
+            qkv = self._linear(L, st, _hip.F32, u, _hip.F32, at.qkv, torch.float32, M).to(adt)
+        else:
+            u = torch.empty(M, Cin, dtype=adt, device=dev)
+            _hip.check(L.mvit_layernorm_fwd(_hip.ptr(x), _hip.ptr(blk.norm1.weight), _hip.ptr(blk.norm1.bias), _hip.ptr(u), M,
+                                            Cin, blk.norm1.eps, act, st), "norm1")
+            qkv = self._linear(L, st, act, u, act, at.qkv, adt, M)
         del u
         # 3. pooling conv + LN of q, k, v straight from the fused buffer   attention.py:241-261
         Tq, Hq, Wq = g.thw_q
         Tk, Hk, Wk = g.thw_kv
         Lq, Lk = g.lq, g.lk
-        q = torch.empty(B, h, Lq, 96, dtype=adt, device=dev)
-        kv = torch.empty(2, B, h, Lk, 96, dtype=adt, device=dev)      # k and v back to back (the pair form of the pooling kernel)
+        pact, pdt = (_hip.F32, torch.float32) if "pool" in ex else (act, adt)
+        if "pool" in ex:
+            qkv = qkv.float()
+        q = torch.empty(B, h, Lq, 96, dtype=pdt, device=dev)
+        kv = torch.empty(2, B, h, Lk, 96, dtype=pdt, device=dev)      # k and v back to back (the pair form of the pooling kernel)
         k, v = kv[0], kv[1]
         kv_batch = g.stride_kv[1] == 2 and os.environ.get("MVIT_POOL_KV_BATCH", "1") != "0"
         pools = [] if kv_batch else [(1, k, at.pool_k, at.norm_k, g.stride_kv[1]), (2, v, at.pool_v, at.norm_v, g.stride_kv[1])]
         if g.kernel_q:
             pools.insert(0, (0, q, at.pool_q, at.norm_q, g.stride_q[1]))
         else:       # pool_q is None (Q_POOL_ALL off): the query is the head-split slice itself, no LayerNorm (attention.py:14-15)
-            _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, act, st), "head_split")
+            _hip.check(L.mvit_head_split_fwd(_hip.ptr(qkv), 3 * Cout, 0, _hip.ptr(q), B, h, N, pact, st), "head_split")
         # the three pooling convs are independent readers of qkv: k and v go to the library's side stream, q stays here
         forked = (not getattr(self, "_substreams_active", False)) and L.mvit_side_fork(st) == 0    # (one side stream: not under sub-batch streams)
         side = L.mvit_side_stream() if forked else st
         for which, buf, conv, norm, stride in pools:
             _hip.check(L.mvit_pool_conv_ln_fwd(_hip.ptr(qkv), 3 * Cout, which * Cout, _hip.ptr(conv.weight),
                                                _hip.ptr(norm.weight), _hip.ptr(norm.bias), _hip.ptr(buf), B, h, T, H, W,
-                                               stride, norm.eps, act, st if which == 0 else side), "pool%d" % which)
+                                               stride, norm.eps, pact, st if which == 0 else side), "pool%d" % which)
         if kv_batch:      # k and v pooling conv + LayerNorm in one launch (no saved statistics in inference)
             _hip.check(L.mvit_pool_conv_ln_fwd_train_kv(_hip.ptr(qkv), 3 * Cout, Cout, _hip.ptr(at.pool_k.weight), _hip.ptr(at.norm_k.weight),
                                                         _hip.ptr(at.norm_k.bias), _hip.ptr(at.pool_v.weight), _hip.ptr(at.norm_v.weight),
                                                         _hip.ptr(at.norm_v.bias), _hip.ptr(kv), None, None, B, h, T, H, W, g.stride_kv[1],
-                                                        at.norm_k.eps, act, side), "pool_kv")
+                                                        at.norm_k.eps, pact, side), "pool_kv")
         if forked:
             _hip.check(L.mvit_side_join(st), "side_join")
         del qkv
+        if "pool" in ex:
+            q, kv = q.to(adt), kv.to(adt)
+            k, v = kv[0], kv[1]
         # 4. fused attention (+ pooled-q residual), heads merged on store   attention.py:267-279
-        o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
-        _hip.check(_hip.attention_fwd(L, q, k, v, o, None, B, h, Lq, Lk, 96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st),
-                   "attention")
+        if "attention" in ex:
+            o = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(_hip.attention_fwd(L, q.float(), k.float(), v.float(), o, None, B, h, Lq, Lk, 96 ** -0.5,
+                                          1 if self.use_query_residual_pool else 0, _hip.F32, st), "attention")
+            o = o.to(adt)
+        else:
+            o = torch.empty(B * Lq, Cout, dtype=adt, device=dev)
+            _hip.check(_hip.attention_fwd(L, q, k, v, o, None, B, h, Lq, Lk, 96 ** -0.5, 1 if self.use_query_residual_pool else 0, act, st),
+                       "attention")
         if taps is not None:
             taps["block%d.q" % g.index] = q
             taps["block%d.k" % g.index] = k
@@ -554,18 +578,27 @@ class MViT(nn.Module):
         # 5. skip path: channel expand on the un-normed x, then max-pool     attention.py:424-432
         r = x.view(M, Cin)
         from ..autograd import _skip_fused
-        if _skip_fused(g, act, B):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
+        sact = _hip.F32 if "skip" in ex else act
+        if _skip_fused(g, sact, B):          # widen + max-pool in one kernel (csrc/skip_pool.hip): the widened tensor never reaches HBM
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_proj_maxpool_fwd(_hip.ptr(r), _hip.ptr(self._w(blk.proj_max_pool.weight, act)),
                                                _hip.ptr(blk.proj_max_pool.bias), _hip.ptr(rp), None, None, B, T, H, W, Cin, Cout, act, st),
                        "proj_maxpool")
             r = rp
         elif g.expand:
-            r = self._linear(L, st, act, r, _hip.F32, blk.proj_max_pool, torch.float32, M)
-        if not g.skip_is_identity and not _skip_fused(g, act, B):
+            r = self._linear(L, st, sact, r, _hip.F32, blk.proj_max_pool, torch.float32, M)
+        if not g.skip_is_identity and not _skip_fused(g, sact, B):
             rp = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
             _hip.check(L.mvit_maxpool_skip_fwd(_hip.ptr(r), _hip.ptr(rp), B, T, H, W, Cout, st), "maxpool")
             r = rp
+        if "tail" in ex:                    # proj + residual, norm2, fc1 + GELU, fc2 + residual on the exact kernels (four launches)
+            y = self._linear(L, st, _hip.F32, o.float(), _hip.F32, at.proj, torch.float32, B * Lq, residual=r)
+            vn = torch.empty(B * Lq, Cout, dtype=torch.float32, device=dev)
+            _hip.check(L.mvit_layernorm_fwd(_hip.ptr(y), _hip.ptr(blk.norm2.weight), _hip.ptr(blk.norm2.bias), _hip.ptr(vn),
+                                            B * Lq, Cout, blk.norm2.eps, _hip.F32, st), "norm2")
+            hid = self._linear(L, st, _hip.F32, vn, _hip.F32, blk.mlp.fc1, torch.float32, B * Lq, gelu=True)
+            out = self._linear(L, st, _hip.F32, hid, _hip.F32, blk.mlp.fc2, torch.float32, B * Lq, residual=y)
+            return out.view(B, Lq, Cout)
         # 6-9 in one kernel where the widths allow: y = r + proj(o) stays in the accumulators, x_out = y + mlp(LN2(y))   attention.py:281,434-445
         tk = self._tail_packed(blk, act)
         if tk is not None:

@@ -275,13 +275,22 @@ class HipAdamW(object):
                     self.state[p][1].copy_(v)
             return
         idx = 0
-        assert sum(len(g["params"]) for g in sd["param_groups"]) == sum(len(g["params"]) for g in self.groups), \
-            "optimizer state has a different number of parameters"
+        # group by group, as torch.optim.Optimizer.load_state_dict checks it ("loaded state dict contains a parameter group that doesn't
+        # match the size of optimizer's group"): `adamw` writes [decay..., no_decay...] in two groups, `zero_adamw` one group in
+        # model.parameters() order -- a checkpoint of one must not be paired index by index with the parameters of the other
+        have, want = [len(g["params"]) for g in sd["param_groups"]], [len(g["params"]) for g in self.groups]
+        if have != want:
+            raise ValueError("loaded optimizer state has parameter groups of sizes %s, this optimizer (SOLVER.OPTIMIZING_METHOD %s) has %s"
+                             % (have, self.cfg.SOLVER.OPTIMIZING_METHOD, want))
         self.lr = float(sd["param_groups"][0]["lr"])
         for grp in self.groups:
-            for p in grp["params"]:
+            for n, p in zip(grp["names"], grp["params"]):
                 ent = sd["state"].get(idx)
                 if ent is not None and p in self.state:     # torch omits entries of parameters that never received a gradient
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if tuple(ent[key].shape) != tuple(p.shape):      # Tensor.copy_ would broadcast a [C] moment into a [N, C] slot
+                            raise ValueError("optimizer state %d (%s): %s has shape %s, the parameter %s" % (
+                                idx, n, key, tuple(ent[key].shape), tuple(p.shape)))
                     self.state[p][0].copy_(ent["exp_avg"])
                     self.state[p][1].copy_(ent["exp_avg_sq"])
                     self.step_count = int(float(ent["step"]))
@@ -376,25 +385,38 @@ class HipZeroAdamW(HipAdamW):
         return set(self.shards[self.rank])
 
     def _after_update(self):
+        """The owners hand out their updated shards: one persistent flat buffer per owner (allocated once), the owner packs its
+        shard into it (one pass over 1 / world of the parameters), all broadcasts are issued asynchronously and waited for once,
+        the other ranks copy the received values into their parameters (one multi-tensor copy per owner)."""
         if self.world == 1:
             return
         import torch.distributed as dist
-        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        if getattr(self, "_flat", None) is None:
+            self._flat = [None if not shard else torch.empty(sum(p.numel() for p in shard), dtype=shard[0].dtype, device=shard[0].device)
+                          for shard in self.shards]
+        works = []
         for r, shard in enumerate(self.shards):
             if not shard:
                 continue
-            flat = _flatten_dense_tensors([p.data for p in shard])
-            dist.broadcast(flat, src=r)
-            if r != self.rank:
-                for p, new in zip(shard, _unflatten_dense_tensors(flat, [p.data for p in shard])):
-                    p.data.copy_(new)
+            if r == self.rank:
+                torch.cat([p.data.reshape(-1) for p in shard], out=self._flat[r])
+            works.append(dist.broadcast(self._flat[r], src=r, async_op=True))
+        for w in works:
+            w.wait()
+        for r, shard in enumerate(self.shards):
+            if shard and r != self.rank:
+                views = [v.view_as(p) for v, p in zip(self._flat[r].split([p.numel() for p in shard]), shard)]
+                torch._foreach_copy_([p.data for p in shard], views)
 
     def consolidate_state_dict(self, to=0):
-        """Gathers every shard's moments on rank ``to`` (collective).  Afterwards ``state_dict()`` on that rank is the full
-        ``torch.optim.AdamW`` layout."""
+        """Gathers every shard's moments on rank ``to`` (collective: every rank calls it).  The gathered moments live in a temporary
+        table that the NEXT ``state_dict()`` on that rank consumes (full ``torch.optim.AdamW`` layout) and drops: rank ``to`` goes
+        back to holding its own shard only, and a later ``state_dict()`` without a fresh consolidation is the shard again, never a
+        stale copy of the other ranks' moments under the current step count."""
         if self.world == 1:
             return
         import torch.distributed as dist
+        gathered = {}
         for r, shard in enumerate(self.shards):
             for p in shard:
                 if r == to:
@@ -404,9 +426,22 @@ class HipZeroAdamW(HipAdamW):
                 elif self.rank == to:
                     buf = torch.empty((2,) + tuple(p.shape), dtype=p.dtype, device=p.device)
                     dist.recv(buf, src=r)
-                    self.state[p] = (buf[0], buf[1])
+                    gathered[p] = (buf[0], buf[1])
         if self.rank == to:
-            self._consolidated = True
+            self._gathered = gathered
+
+    def state_dict(self):
+        gathered = getattr(self, "_gathered", None)
+        if not gathered:
+            return super().state_dict()                 # this rank's shard
+        own = self.state
+        try:
+            self.state = dict(own)
+            self.state.update(gathered)
+            return super().state_dict()
+        finally:
+            self.state = own
+            self._gathered = None                       # one-shot: the other ranks' moments are not kept
 
 
 def construct_optimizer(model, cfg):

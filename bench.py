@@ -19,8 +19,8 @@ generated on the device before the timed region; random-init weights from the se
       top-k errors, stat all-reduce, meters, json_stats lines) over a synthetic in-memory loader -- what a user of
       tools/run_net.py gets; must stay within a few % of --mode train (no per-iteration host sync).
   --mode window: BASELINE configs[4]: sliding-window inference over a synthetic 30 s 540p stream x 3 camera views
-      (57 windows of 16x4 frames per view, GPU gather + cv2-style resize to 448 + normalise + forward), the 171 windows
-      sharded over the ranks and gathered ("strong" scaling: the stream is fixed).
+      (57 windows of 16x4 frames per view, GPU gather + cv2-style resize to 448 + normalise + forward), the 171 (view, window)
+      pairs sharded rank-strided over the ranks, one all_gather of the scores ("strong" scaling: the stream is fixed).
 Per-GPU work is fixed as N grows ("weak" scaling); the timed region is bracketed by barrier +
 torch.cuda.synchronize() and the MAX over ranks is reported (wall clock over exactly K steps: the driver's contract; the
 median of per-step HIP-event intervals is given beside it as `ms_per_step_event_median`).  Rank 0 prints ONE JSON
@@ -140,7 +140,7 @@ def main():
         n_windows = 3 * 57
 
         def step():
-            res = [swc.run(v) for v in views]
+            res = swc.run_views(views)          # the 171 (view, window) pairs rank-strided over the ranks, one all_gather, one host copy
             return torch.from_numpy(res[0][0][2])
     elif args.mode == "loop":
         import logging
@@ -410,11 +410,11 @@ def main():
         views = [torch.randint(0, 256, (900, 540, 960, 3), device=dev, dtype=torch.uint8, generator=gs) for _ in range(3)]
         with torch.no_grad():
             prec_w = mw.precision                                 # what run() (no_grad) computes in: HIP.PRECISION auto -> fp16
-        res = [swc.run(v) for v in views]                       # warm-up pass (also the shape check below)
+        res = swc.run_views(views)                              # warm-up pass (also the shape check below)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(2):
-            res = [swc.run(v) for v in views]
+            res = swc.run_views(views)
         torch.cuda.synchronize()
         wdt = (time.perf_counter() - t0) / 2
         window_rec = {"workload": "sliding-window inference: 3 views x 900 frames 540x960 uint8 (synthetic), 57 windows / view of 16 frames (stride 4), "
@@ -515,7 +515,7 @@ def main():
         if args.mode == "window":
             line["config"]["workload"] = ("sliding-window inference: 3 views x 900 frames 540x960 uint8 (synthetic), 57 windows/view of "
                                           "16 frames (stride 4), resize to %d, bf16 forward, batch %d (BASELINE configs[4])" % (args.crop, args.batch))
-            line["config"]["parallelism"] = "dp%d (windows sharded rank-strided, all_gather of [n,18] scores)" % world
+            line["config"]["parallelism"] = "dp%d ((view, window) pairs sharded rank-strided: %d per rank, ONE all_gather of [n,18] scores)" % (world, -(-n_windows // world))
             line["seconds_per_30s_stream_3views"] = round(dt / args.steps, 4)
             line["parity_note"] = ("front end (gather + 8-bit INTER_LINEAR resize + normalise) is bit-exact vs oracle/window_oracle.py; "
                                    "cv2 is absent from this image, so that restatement of cv2.resize is itself unpinned (SURVEY 8f rank 1: parity unpinned)")

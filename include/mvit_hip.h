@@ -30,6 +30,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of the file are
+ * its ONLY dynamic exports (kernel handles, launch helpers and device stubs stay internal). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 enum { MVIT_F32 = 0, MVIT_BF16 = 1 };
 
 enum {
@@ -346,6 +352,10 @@ int mvit_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, in
  * ceil(rows/64)*ceil(cols/64); total_tiles = that sum over all tensors (one workgroup per 64x64 tile). */
 int mvit_cast_desc_bytes(void);
 int mvit_cast_transpose_multi(const void* desc_table, int ntensors, int total_tiles, void* stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

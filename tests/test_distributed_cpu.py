@@ -135,3 +135,80 @@ def test_train_and_test_loops_world2():
     assert res[0][2] == pytest.approx(mean_loss, abs=1e-4)                 # all-reduced (averaged) loss of the global batch
     for r in res:
         assert r[4] == [2, 2] and r[5] == "test_final"                     # both ranks saw all 4 clips
+
+
+class _ToySlider(object):
+    """SlidingWindowClassifier with the GPU front end replaced by a CPU gather (frame means): the sharding / batching / gather logic of
+    run_views() is what runs here."""
+
+    @staticmethod
+    def make(batch_size):
+        from aicity_action_amd.inference import SlidingWindowClassifier
+
+        class S(SlidingWindowClassifier):
+            def preprocess(self, frames_u8, windows, idx=None, out=None):
+                idx = self.window_frame_indices(windows, frames_u8.shape[0], frames_u8.device) if idx is None else idx
+                fr = frames_u8.float().mean(dim=(1, 2))[idx.long()]                     # [n, T, 3]
+                val = fr.permute(0, 2, 1)[:, :, :, None, None].expand(-1, -1, -1, self.frame_size, self.frame_size)
+                if out is None:
+                    return val.contiguous()
+                out.copy_(val)
+                return out
+        torch.manual_seed(0)
+        return S(_ToyNet().eval(), frame_size=4, batch_size=batch_size)
+
+
+def _toy_views():
+    g = torch.Generator().manual_seed(3)
+    return [torch.randint(0, 256, (n, 2, 2, 3), dtype=torch.uint8, generator=g) for n in (900, 900, 610)]
+
+
+def _views_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _ToySlider.make(8).run_views(_toy_views())
+    q.put((rank, [[(a, b, p.tolist()) for a, b, p in r] for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_window_pairs_sharded_over_two_ranks_equal_the_per_view_runs():
+    """BASELINE configs[4] as SURVEY 8(e) shards it: the (view, window) pairs of all views rank-strided over the ranks, ONE all_gather;
+    every rank gets every view's full list, bit-equal to running each view alone in one process (the reference's serial order,
+    run_action_classification_temporal_inf.py:99-130)."""
+    from aicity_action_amd.inference.sliding_window import get_proposals
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_views_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    views = _toy_views()
+    swc = _ToySlider.make(8)
+    ref = [swc.run(v, shard=False) for v in views]
+    one = swc.run_views(views, shard=False)
+    for res in (one, got[0][1], got[1][1]):
+        assert len(res) == 3
+        for v, rr, r in zip(views, ref, res):
+            assert [(a, b) for a, b, _ in r] == get_proposals(v.shape[0], 64, 16) == [(a, b) for a, b, _ in rr]
+            for (_, _, p), (_, _, pr) in zip(r, rr):
+                assert (torch.tensor(p, dtype=torch.float32) == torch.from_numpy(pr)).all()
+
+
+def test_pair_batches_are_balanced_and_cover_every_pair_once():
+    swc = _ToySlider.make(8)
+    assert [b - a for a, b in swc.pair_batches(171)] == [9] * 3 + [8] * 18          # 3 views x 57 windows on one GPU
+    assert [b - a for a, b in swc.pair_batches(22)] == [8, 7, 7]                    # 176 padded pairs / 8 ranks
+    assert len(du.shard_indices(171, 0, 8, pad=True)) == 22                          # 176 slots, not 3 x 64 = 192
+    for bs in (1, 3, 8, 16):
+        s = _ToySlider.make(bs)
+        for n in range(0, 200):
+            bb = s.pair_batches(n)
+            assert [a for a, _ in bb] == [0] * (n > 0) + [b for _, b in bb[:-1]] and (not bb or bb[-1][1] == n)
+            sizes = [b - a for a, b in bb]
+            assert not sizes or (max(sizes) - min(sizes) <= 1 and max(sizes) <= bs + max(bs // 4, 1))

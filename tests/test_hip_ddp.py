@@ -398,6 +398,25 @@ def _zero_worker(rank, world, port, q):
     torch.cuda.synchronize()
     opt.consolidate_state_dict(0)
     sd = opt.state_dict()
+    # the gathered moments are consumed by that one state_dict(): rank 0 is back to its own shard (the ZeRO saving is kept between
+    # checkpoints) and a state_dict() without a fresh consolidation is the shard, never a stale full copy
+    assert sum(p.numel() for p in opt.state) == mine and len(opt.state_dict()["state"]) < len(list(model.parameters()))
+    if rank == 0:       # a checkpoint of the one-group zero_adamw must not be paired index by index with adamw's two groups
+        cfg.SOLVER.OPTIMIZING_METHOD = "adamw"
+        plain = construct_optimizer(model, cfg)
+        try:
+            plain.load_state_dict(sd)
+            raise AssertionError("adamw accepted a zero_adamw state dict")
+        except ValueError as e:
+            assert "parameter groups" in str(e)
+        sd2 = plain.state_dict()
+        first = min(sd2["state"])
+        sd2["state"][first]["exp_avg"] = sd2["state"][first]["exp_avg"].reshape(-1)[:1].clone()
+        try:
+            plain.load_state_dict(sd2)
+            raise AssertionError("a moment of the wrong shape was broadcast into the slot")
+        except ValueError as e:
+            assert "shape" in str(e)
     q.put((rank, mine, total, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}, len(sd["state"]),
            {i: e["exp_avg_sq"].cpu().numpy() for i, e in sd["state"].items()} if rank == 0 else None))
     dist.barrier()

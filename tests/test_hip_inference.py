@@ -169,3 +169,45 @@ def test_sliding_window_sharded_over_two_ranks_equals_one_rank():
     assert [(a, b) for a, b, _ in got] == [(r[0], r[1]) for r in ref] == get_proposals(300, 64, 16)
     for (_, _, p), r in zip(got, ref):
         assert np.abs(np.asarray(p, dtype=np.float32) - r[2]).max() <= 1e-6
+
+
+def _view_pairs_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    views = [torch.randint(0, 256, (n, 540, 960, 3), device="cuda", dtype=torch.uint8, generator=g) for n in (100, 100, 70)]
+    res = SlidingWindowClassifier(_full448_model(), frame_size=448, batch_size=8).run_views(views)
+    if rank == 0:
+        q.put([[(t0, t1, p.tolist()) for t0, t1, p in r] for r in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_window_pairs_over_two_ranks_equal_each_view_alone():
+    """configs[4] sharded as SURVEY 8(e) writes it: (view, window) pairs of three views rank-strided over two gloo ranks on this GPU
+    (batches cross view boundaries, one all_gather, one host copy) == every view run alone in one process, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_view_pairs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=600)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    g = torch.Generator(device="cuda").manual_seed(8)
+    views = [torch.randint(0, 256, (n, 540, 960, 3), device="cuda", dtype=torch.uint8, generator=g) for n in (100, 100, 70)]
+    swc = SlidingWindowClassifier(_full448_model(), frame_size=448, batch_size=8)
+    one = swc.run_views(views, shard=False)
+    for v, r1, r2 in zip(views, one, got):
+        ref = swc.run(v, shard=False)
+        assert [(a, b) for a, b, _ in r2] == [(a, b) for a, b, _ in ref] == [(a, b) for a, b, _ in r1] == get_proposals(v.shape[0], 64, 16)
+        for (_, _, p2), (_, _, p1), (_, _, pr) in zip(r2, r1, ref):
+            assert np.array_equal(np.asarray(p2, dtype=np.float32), pr) and np.array_equal(p1, pr)

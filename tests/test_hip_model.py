@@ -229,6 +229,46 @@ def test_logit_gate_over_seeds_and_a_trained_like_model():
     assert a16 <= 2.5e-3
 
 
+def test_fp16_error_budget_per_kernel_family():
+    """Which kernel family contributes what to the fp16 logit error (gate 1e-3; worst gate case: 224, weight seed 1, clip seed 101).
+    ``MViT._exact_ops`` puts ONE op family of the 16-bit forward on the exact-fp32 kernels (inputs widened, outputs rounded back to
+    half where the next kernel reads 16 bit); the error that disappears is what that family's 16-bit arithmetic costs.  The table is
+    committed as profiles/r6_fp16_error_budget.txt; the total must stay <= 9e-4 (10 % under the gate) and the instrument itself is
+    checked: with every family exact only the roundings at the six hand-over points remain."""
+    import os
+    from conftest import ROOT
+    from aicity_action_amd.config import load_config
+    cases = [c for c in _gate_cases() if not c["stressed"]]
+    fams = ("stem", "qkv", "pool", "attention", "skip", "tail")
+    print("\nfp16 logit error with ONE kernel family on the exact-fp32 kernels (max |logit - reference|)")
+    print(" crop wseed cseed   product   " + "  ".join("%-9s" % f for f in fams) + "  all-exact")
+    worst_total, worst_row = 0.0, None
+    for c in cases:
+        if c["crop"] != 224:
+            continue            # (the 448 cases cost 4x; the worst case of the gate set is a 224 one)
+        ref = np.array(c["logits"], np.float32).reshape(1, -1)
+        clip = synth_clip(1, c["num_frames"], c["crop"], c["clip_seed"]).cuda()
+        cfg = load_config(os.path.join(ROOT, "configs", "Aicity", c["yaml"]), ["NUM_GPUS", 1, "HIP.PRECISION", "auto"])
+        model = build_model(cfg).eval()
+        load_synth_weights(model, c["weight_seed"])
+        errs = []
+        with torch.no_grad():
+            assert model.precision == "fp16"
+            for ex in [()] + [(f,) for f in fams] + [fams]:
+                model._exact_ops = frozenset(ex)
+                _, logits = model._forward_hip(clip, return_logits=True)
+                errs.append(float(np.abs(logits.float().cpu().numpy() - ref).max()))
+        model._exact_ops = frozenset()
+        print(" %4d %5d %5d   %.2e  " % (c["crop"], c["weight_seed"], c["clip_seed"], errs[0]) + "  ".join("%.2e " % e for e in errs[1:]))
+        if errs[0] > worst_total:
+            worst_total, worst_row = errs[0], errs
+        assert errs[-1] <= 0.75 * errs[0] + 5e-5, errs       # the instrument removes error: what is left are the hand-over roundings
+        del model
+    gain = {f: worst_row[0] - worst_row[1 + i] for i, f in enumerate(fams)}
+    print("worst case %.3e; error removed by making one family exact: " % worst_total + ", ".join("%s %+.1e" % kv for kv in gain.items()))
+    assert worst_total <= 9e-4
+
+
 def test_fp16_auto_inference_raises_on_non_finite_output():
     """HIP.PRECISION auto picks IEEE half for any checkpoint; half overflows beyond 65504.  A model whose activations leave that range
     must not return NaN probabilities silently: the deferred guard raises (at check_finite(), or at the next forward), with the hint
