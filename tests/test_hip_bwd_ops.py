@@ -178,7 +178,7 @@ def test_attention_bwd(hip_lib, act, B, h, Lq, Lk, add_q):
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("B,h,T,H,W,s", [(2, 1, 2, 16, 16, 1), (1, 2, 2, 14, 14, 2), (2, 2, 3, 7, 7, 2), (1, 1, 2, 14, 14, 4),
-                                         (1, 2, 2, 5, 9, 1)])
+                                         (1, 2, 2, 5, 9, 1), (1, 2, 3, 14, 14, 1), (2, 1, 4, 28, 28, 1), (1, 1, 2, 28, 14, 1)])
 def test_pool_conv_ln_bwd(hip_lib, act, B, h, T, H, W, s):
     C = 96 * h
     N = T * H * W

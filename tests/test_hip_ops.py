@@ -299,7 +299,9 @@ def test_linear_rejects_bad_shapes(hip_lib):
 
 @pytest.mark.parametrize("act", [_hip.F32, _hip.BF16])
 @pytest.mark.parametrize("B,h,T,H,W,s", [(2, 1, 2, 16, 16, 1), (1, 2, 2, 14, 14, 2), (2, 2, 3, 7, 7, 2),
-                                         (1, 4, 2, 14, 14, 4), (1, 1, 8, 28, 28, 8), (1, 2, 2, 5, 9, 1)])
+                                         (1, 4, 2, 14, 14, 4), (1, 1, 8, 28, 28, 8), (1, 2, 2, 5, 9, 1),
+                                         # stride-1 grids whose height is a multiple of 14: the full-lane march kernel (16-bit builds)
+                                         (1, 2, 3, 14, 14, 1), (2, 1, 4, 28, 28, 1), (1, 1, 2, 28, 14, 1), (1, 1, 1, 14, 7, 1)])
 def test_pool_conv_ln(hip_lib, act, B, h, T, H, W, s):
     C = 96 * h
     N = T * H * W
