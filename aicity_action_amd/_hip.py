@@ -133,11 +133,38 @@ def lib(half="bf16"):
     return _lib
 
 
+# bench.py's in-step roofline: when this is a list, every fused-attention launch of the model is bracketed by two timing events on
+# its launch stream and (kind, algorithmic FLOPs, event, event) is appended -- what the kernels cost INSIDE a step, between the
+# step's other launches and beside its side streams.  None (the default) = no events, no overhead.
+ATT_TIMER = None
+
+
+def _att_timed(kind, flops, fn):
+    if ATT_TIMER is None:
+        return fn()
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    ATT_TIMER.append((kind, flops, e0, e1))
+    return rc
+
+
 def attention_fwd(L, q, k, v, o, lse, B, h, Lq, Lk, scale, add_q, act, st):
     """mvit_attention_fwd on torch tensors.  (A key-split form of the ragged last query tile was measured in round 4 -- stage-3 forward
     168.2 -> 158.9 us at B = 8 but 77.5 -> 96 us for the 3-clip sub-batches of the inference path, and the choice may not depend on the
     batch -- and left the library in round 5: tools/probes/attn_fwd_keysplit.patch, profiles/r4_attn_tail.txt.)"""
-    return L.mvit_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, st)
+    return _att_timed("fwd", 4.0 * B * h * Lq * Lk * 96,
+                      lambda: L.mvit_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, h, Lq, Lk, scale, add_q, act, st))
+
+
+def attention_bwd(L, q, k, v, o, lse, d_o, dq, dk, dv, ws, B, h, Lq, Lk, scale, add_q, act, st):
+    """mvit_attention_bwd on torch tensors (delta / dQ pass / dK,dV pass: everything is ordered on `st` again when it returns).  Credited
+    FLOPs = 2 x the forward's (the recomputed products are not credited)."""
+    return _att_timed("bwd", 8.0 * B * h * Lq * Lk * 96,
+                      lambda: L.mvit_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(d_o), ptr(dq), ptr(dk), ptr(dv), ptr(ws),
+                                                   B, h, Lq, Lk, scale, add_q, act, st))
 
 
 def check(rc, what=""):

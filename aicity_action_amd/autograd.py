@@ -449,8 +449,7 @@ class _BlockFn(torch.autograd.Function):
         dkv = torch.empty(2, B, h, Lk, 96, dtype=k.dtype, device=dev)
         dk, dv = dkv[0], dkv[1]
         ws = _ws(L.mvit_attention_bwd_workspace_bytes(B, h, Lq, Lk), dev)
-        _hip.check(L.mvit_attention_bwd(_hip.ptr(q), _hip.ptr(k), _hip.ptr(v), _hip.ptr(o), _hip.ptr(lse), _hip.ptr(d_o), _hip.ptr(dq),
-                                        _hip.ptr(dk), _hip.ptr(dv), _hip.ptr(ws), B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
+        _hip.check(_hip.attention_bwd(L, q, k, v, o, lse, d_o, dq, dk, dv, ws, B, h, Lq, Lk, 96 ** -0.5, ctx.addq, act, _st()),
                    "attention_bwd")
         del d_o
         d_qkv = torch.empty(M, 3 * Cout, dtype=adt, device=dev)

@@ -503,8 +503,24 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
 }
 
+#ifndef BIG_ABL
+#define BIG_ABL 0      // timing ablations of linear_big_kernel (tools/r6_big_ab.sh; results invalid): 1 no epilogue stores, 2 no aux loads, 4 aux loads NOT prefetched (round-5 form),
+                       // 8 stores as contiguous 1-KiB runs (wrong places, same bytes), 16 aux loads as contiguous 1-KiB runs (wrong data, same bytes),
+                       // 32 one workgroup of a CU in its main loop at a time (per-CU token; results VALID)
+#endif
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
+#if BIG_ABL & 32
+// Probe: a per-CU token around the main loop.  The two workgroups of a CU share the matrix pipes, which pulls them into lock-step (the
+// one ahead slows down whenever both multiply, the one behind speeds up whenever the other stores): main loops together, then epilogues
+// together, memory idle in the first phase and the matrix cores in the second.  With the token only one of them multiplies at a time.
+__device__ unsigned g_cu_token[16 * 256];
+__device__ __forceinline__ unsigned cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // XCC_ID [3:0]
+    return (xcc & 15u) * 256u + ((hw >> 8) & 255u);
+}
+#endif
 template <typename TO, bool RES, bool SCALE, int DG = 0>     // DG: 1 = aux is the pre-activation, 2 = aux is GELU'(pre) already
 __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ w, const float* __restrict__ bias,
@@ -592,11 +608,59 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     // and its first two k-steps -- columns the previous slab already covered -- are multiplied with zeroed token fragments
     const int nk = (K + G_BK - 1) / G_BK;
     const bool ktail = (K & (G_BK - 1)) != 0;
+    // DG: the epilogue multiplies every output by a 16-bit operand of the output's shape (the saved GELU' / the pre-activation).  Round 6:
+    // its twelve 16-byte loads per lane are REQUESTED UNDER THE MAIN LOOP (behind the DMA of slab 1, so that slab 1's wait may leave
+    // them outstanding: vmcnt retires in order) instead of after the last MFMA, where both workgroups of a CU sat out the full memory
+    // latency together before their first store (profiles/r6_gemm_big_prefetch_ab.txt).  48 registers; the kernel has 256.
+    constexpr bool PREFETCH = DG != 0 && !(BIG_ABL & 4) && !(BIG_ABL & 2);
+    [[maybe_unused]] uint4 pre_all[PREFETCH ? 2 : 1][3][2];
+    // fp32 output with a residual: the residual row piece of the FIRST 32-row block (twelve 16-byte loads, 48 registers) is requested the
+    // same way; the second block's is requested at the top of the epilogue, in front of the first block's arithmetic and stores
+    constexpr bool PREFETCH_R = sizeof(TO) == 4 && RES && !(BIG_ABL & 4) && !(BIG_ABL & 2);
+    [[maybe_unused]] float4 rr_pre[PREFETCH_R ? 3 : 1][PREFETCH_R ? 4 : 1];
     dma(0, 0);
+#if BIG_ABL & 32
+    const unsigned ckey = cu_key();
+    if (tid == 0) {
+        while (atomicCAS(&g_cu_token[ckey], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
+        if ((PREFETCH || PREFETCH_R) && kt == 1 && nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slab 1 has landed; the 12 younger loads may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
         __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other buffer
         if (kt + 1 < nk) dma((ktail && kt + 2 == nk) ? K - G_BK : (kt + 1) * G_BK, (kt + 1) & 1);
+        if constexpr (PREFETCH) {
+            if (kt == 0) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    int64_t m = m0 + 64 * wm + 32 * mb + r;
+                    m = (full_m || m < M) ? m : M - 1;
+                    const bf16_t* pre = reinterpret_cast<const bf16_t*>(residual) + m * ldr + n0 + 96 * wn;
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if constexpr (BIG_ABL & 16) {
+                                const int run = ((wave * 2 + mb) * 3 + nb) * 2 + qq, piece = run * 64 + lane;
+                                const int prow = piece / 24, pc = piece - prow * 24;
+                                pre_all[mb][nb][qq] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(residual) + (m0 + prow) * ldr + n0 + 8 * pc);
+                            } else
+                            pre_all[mb][nb][qq] = *reinterpret_cast<const uint4*>(pre + 32 * nb + 8 * (2 * qq + h));
+                        }
+                }
+            }
+        }
+        if constexpr (PREFETCH_R) {
+            if (kt == 0) {
+                int64_t m = m0 + 64 * wm + r;
+                m = (full_m || m < M) ? m : M - 1;
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr_pre[nb][q] = load4(residual + m * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+            }
+        }
         const bool half = ktail && kt + 1 == nk;
         const uint32_t bo = (kt & 1) ? G_BUF : 0;
         bf16x8 xf[4][2], wf[4][3];
@@ -625,6 +689,10 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
 #undef MM
     }
 
+#if BIG_ABL & 32
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) atomicExch(&g_cu_token[ckey], 0u);
+#endif
     if (epilogue & 256) {   // DIAG build aid: skip the epilogue, keep the accumulators live
         float t = 0.f;
 #pragma unroll
@@ -650,10 +718,33 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                 if (SCALE) sc = row_scale[m / rows_per_scale];
                 float4 rr[3][4];
                 if (RES) {
+                    if (PREFETCH_R && mb == 0) {           // block 0: requested under the main loop; block 1: request it now, use it after block 0's stores
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb)
+                        for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) rr[nb][q] = load4(residual + m * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+                            for (int q = 0; q < 4; ++q) rr[nb][q] = rr_pre[PREFETCH_R ? nb : 0][PREFETCH_R ? q : 0];
+                        int64_t m1 = m0 + 64 * wm + 32 + r;
+                        m1 = (decltype(full_tag)::value || m1 < M) ? m1 : M - 1;
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rr_pre[PREFETCH_R ? nb : 0][PREFETCH_R ? q : 0] = load4(residual + m1 * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+                    } else if (PREFETCH_R) {
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rr[nb][q] = rr_pre[PREFETCH_R ? nb : 0][PREFETCH_R ? q : 0];
+                    } else if (BIG_ABL & 2) {
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rr[nb][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    } else {
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rr[nb][q] = load4(residual + m * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+                    }
                 }
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
@@ -663,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                         if (decltype(gelu_tag)::value) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
                         if (SCALE) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
                         if (RES) { v.x += rr[nb][q].x; v.y += rr[nb][q].y; v.z += rr[nb][q].z; v.w += rr[nb][q].w; }
-                        if (ok) *reinterpret_cast<float4*>(y + m * ldy + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q) = v;
+                        if ((BIG_ABL & 1) ? (ok && v.x == 12345.678f) : ok) *reinterpret_cast<float4*>(y + m * ldy + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q) = v;
                     }
             }
         };
@@ -681,12 +772,24 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         const bool ok = full_m || m < M;
         const float sc = (row_scale && ok) ? row_scale[m / rows_per_scale] : 1.f;
         [[maybe_unused]] uint4 pre_raw[3][2];
-        if constexpr (DG) {     // the six 16-byte pieces of this row's pre-activation, in the OUTPUT piece layout, all requested first
-            const bf16_t* pre = reinterpret_cast<const bf16_t*>(residual) + (ok ? m : M - 1) * ldr + n0 + 96 * wn;
+        if constexpr (DG) {     // the six 16-byte pieces of this row's pre-activation, in the OUTPUT piece layout
+            if constexpr (PREFETCH) {
 #pragma unroll
-            for (int nb = 0; nb < 3; ++nb)
+                for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq) pre_raw[nb][qq] = *reinterpret_cast<const uint4*>(pre + 32 * nb + 8 * (2 * qq + h));
+                    for (int qq = 0; qq < 2; ++qq) pre_raw[nb][qq] = pre_all[mb][nb][qq];
+            } else if constexpr (BIG_ABL & 2) {
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) pre_raw[nb][qq] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+            } else {            // (round-5 form: all requested here, after the main loop)
+                const bf16_t* pre = reinterpret_cast<const bf16_t*>(residual) + (ok ? m : M - 1) * ldr + n0 + 96 * wn;
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) pre_raw[nb][qq] = *reinterpret_cast<const uint4*>(pre + 32 * nb + 8 * (2 * qq + h));
+            }
         }
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
@@ -749,7 +852,13 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
                     const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     // lower half: {own q lo4 | upper's q (cols +4)} ; upper half: {lower's q+1 | own q+1 (cols +4)}
                     const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    if (ok) *reinterpret_cast<uint4*>(y + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (q + h)) = o;
+                    if constexpr (BIG_ABL & 8) {
+                        // the tile's 48 KiB as 48 runs of 1 KiB: run = (wave, mb, nb, q/2), lane-linear inside; rows of the tile are ldy apart, a tile row holds 384 B
+                        const int run = ((wave * 2 + mb) * 3 + nb) * 2 + (q >> 1), piece = run * 64 + lane;      // 16-byte piece index 0..3071 inside the tile
+                        const int prow = piece / 24, pc = piece - prow * 24;
+                        *reinterpret_cast<uint4*>(y + (m0 + prow) * ldy + n0 + 8 * pc) = o;
+                    } else
+                    if ((BIG_ABL & 1) ? (o.x == 0x12345678u && ok) : ok) *reinterpret_cast<uint4*>(y + m * ldy + (n0 + 96 * wn + 32 * nb) + 8 * (q + h)) = o;
                 }
             }
         }

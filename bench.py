@@ -240,6 +240,23 @@ def main():
     if args.mode == "window":
         clips_per_s = n_windows * args.steps / dt
 
+    # ---- in-step cost of the dominant family: one EXTRA step (after the K timed ones) with two HIP events around every fused-attention
+    # launch, recorded on the stream the launch goes to (the sub-batch streams of the inference forward included) ------------------------
+    instep = None
+    if rank == 0 and not args.no_kernel_timing and args.mode in ("train", "fwd"):
+        _hip.ATT_TIMER = []
+        try:
+            step()
+            torch.cuda.synchronize()
+            rec = _hip.ATT_TIMER
+        finally:
+            _hip.ATT_TIMER = None
+        instep = {}
+        for kind in ("fwd", "bwd"):
+            rows = [(fl, e0.elapsed_time(e1)) for k_, fl, e0, e1 in rec if k_ == kind]
+            if rows:
+                instep[kind] = {"launches": len(rows), "flops": sum(r_[0] for r_ in rows), "ms": sum(r_[1] for r_ in rows)}
+
     # ---- dominant kernel family (fused attention): live HIP-event timing on the launch stream -------------------
     # fwd mode : attn_fwd kernel, algorithmic FLOPs = sum_blocks 4*B*h*Lq*Lk*96.
     # train    : the attention backward (delta + dQ pass + dK/dV pass per block) is the largest item of the step;
@@ -311,19 +328,31 @@ def main():
             except Exception:
                 return None
 
-        def rl(name, tot_flops, tot_ms, per_block, traffic=None):
-            ach = tot_flops / (tot_ms * 1e-3) / 1e12
-            return {"kernel": name, "timed": "alone, randn operands, back to back on the launch stream (the in-step figure is in profiles/: kernels run "
-                                             "5-10 % slower between the step's other launches)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "launches": len(flops) * sub, "clips_per_launch": clips_pl, "avg_launch_ms": round(tot_ms / len(flops), 4),
-                    "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block": per_block}
+        def rl(name, tot_flops, tot_ms, per_block, traffic=None, inst=None):
+            """`achieved` / `frac` = the IN-STEP figure when the extra instrumented step ran (HIP events around every launch of the family
+            inside a real step: between the step's other launches, beside its side streams); `achieved_alone` / `frac_alone` = the same
+            kernels on randn operands, back to back with nothing else on the GPU."""
+            ach_alone = tot_flops / (tot_ms * 1e-3) / 1e12
+            ach = ach_alone if inst is None else inst["flops"] / (inst["ms"] * 1e-3) / 1e12
+            d = {"kernel": name,
+                 "timed": ("in-step: two HIP events around every launch of this family during one extra step after the K timed ones, on the launch's own stream; "
+                           "`*_alone`: randn operands, back to back on an otherwise idle GPU") if inst is not None else
+                          "alone, randn operands, back to back on the launch stream",
+                 "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                 "achieved_alone": round(ach_alone, 2), "frac_alone": round(ach_alone / peak, 4), "traffic": traffic,
+                 "launches": len(flops) * sub, "clips_per_launch": clips_pl, "avg_launch_ms": round(tot_ms / len(flops), 4),
+                 "algorithmic_gflop_per_launch_avg": round(tot_flops / len(flops) / 1e9, 2), "tflops_per_block_alone": per_block}
+            if inst is not None:
+                d["in_step_ms"] = round(inst["ms"], 4)
+                d["in_step_launches"] = inst["launches"]
+                d["alone_ms"] = round(tot_ms, 4)        # one launch per block at `clips_per_launch` clips (in-step: every launch of the step)
+            return d
         sfx = args.precision if act else "f32"
         fwd_rl = rl("attn_fwd_w64_kernel (%s)" % sfx if act else "attn_fwd_f32_kernel", sum(flops), fwd_ms, per_f,
-                    pmc_traffic(TRAFFIC_FWD, "traffic_bytes_per_launch", "attention_fwd"))
+                    pmc_traffic(TRAFFIC_FWD, "traffic_bytes_per_launch", "attention_fwd"), (instep or {}).get("fwd"))
         if train:
             roofline = rl("mvit_attention_bwd (attn_bwd_delta + attn_bwd_dq + attn_bwd_dkv kernels, %s)" % sfx, 2 * sum(flops), bwd_ms, per_b,
-                          pmc_traffic(TRAFFIC_BWD, "traffic_bytes_per_call", "attention_bwd"))
+                          pmc_traffic(TRAFFIC_BWD, "traffic_bytes_per_call", "attention_bwd"), (instep or {}).get("bwd"))
             extra_rooflines["roofline_attention_fwd"] = fwd_rl
         else:
             roofline = fwd_rl
