@@ -4,7 +4,6 @@ ActionProposalFromVideoTemporalDataset), minus video decoding: the input is an a
 the GPU.  Window list, frame sampling, resize and normalisation follow the reference exactly; the per-window work
 (gather + resize + normalise, then the MViT forward) runs in HIP kernels, batched, and windows are sharded over ranks.
 """
-import os
 import pickle
 
 import numpy as np
@@ -111,21 +110,10 @@ class SlidingWindowClassifier(object):
                                for j in mine]).to(torch.int32).to(dev)
         S = self.frame_size
         probs = []
-        # The front end of batch i + 1 runs UNDER the forward of batch i: it is enqueued, right after that forward's launches, on the LAST of
-        # the model's sub-batch streams -- the one that carries the smallest share of a batch (8 clips on 3 streams = 3, 3, 2) and would
-        # otherwise idle until its neighbours finish.  No extra stream is created (a fifth stream would share a hardware queue with one
-        # of the forward's four); the forward waits for its clips through one event.  MVIT_WINDOW_PREFETCH=0: everything on the caller's stream.
-        core0 = self.model.module if hasattr(self.model, "module") else self.model
-        ns = int(getattr(core0, "eval_streams", 1))
-        ahead = views[0].is_cuda and ns > 1 and os.environ.get("MVIT_WINDOW_PREFETCH", "1") != "0"
-        pre_stream = _hip.shared_streams(dev, ns)[-1] if ahead else None
-        cur = torch.cuda.current_stream(dev) if views[0].is_cuda else None
-        if ahead:                               # the index table (and whatever produced the views) was enqueued under the caller's stream: ordered once
-            ev0 = torch.cuda.Event()
-            ev0.record(cur)
-            pre_stream.wait_event(ev0)
-
-        def front_end(i0, i1):
+        # (Measured and not kept, round 6: the front end of batch i + 1 enqueued under the forward of batch i on the least-loaded sub-batch
+        # stream -- 706.1 / 706.5 against 709.4 / 704.4 clips/s for the serial order, profiles/r6_window_prefetch_ab.txt: the front end is
+        # ~1 % of a batch; what separates this path from the bare forward's rate is the drain at the one host copy per call.)
+        for i0, i1 in self.pair_batches(len(mine)):
             clips = torch.empty(i1 - i0, 3, self.frame_length, S, S, dtype=torch.float32, device=dev)
             a = i0
             while a < i1:                       # runs of one view inside the batch: one gather + resize launch each
@@ -135,25 +123,7 @@ class SlidingWindowClassifier(object):
                     b += 1
                 self.preprocess(views[vi], [wins[vi][pairs[mine[j]][1]] for j in range(a, b)], idx_all[a:b], out=clips[a - i0:b - i0])
                 a = b
-            return clips
-
-        batches = self.pair_batches(len(mine))
-        nxt = None
-        for bi, (i0, i1) in enumerate(batches):
-            if nxt is None:
-                clips = front_end(i0, i1)
-            else:
-                clips, ev = nxt
-                cur.wait_event(ev)
-                clips.record_stream(cur)        # allocated under the sub-batch stream, consumed from here on under the caller's
             probs.append(self.model([clips]).float())
-            nxt = None
-            if ahead and bi + 1 < len(batches):
-                with torch.cuda.stream(pre_stream):     # behind this stream's share of the forward just enqueued, beside the other shares
-                    c2 = front_end(*batches[bi + 1])
-                    ev = torch.cuda.Event()
-                    ev.record()
-                nxt = (c2, ev)
         probs = torch.cat(probs, 0)
         ids = list(mine)
         if world > 1:

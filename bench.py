@@ -42,9 +42,9 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_CLIP = {448: 856.45, 224: 127.73}   # SURVEY.md section 8d (2 FLOP/MAC, GEMM + conv terms)
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FWD = "r5_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh via tools/r5_profiles.sh)
-TRAFFIC_BWD = "r5_attn_bwd_hbm_traffic.json"
-TRAFFIC_TAIL = "r5_block_tail_hbm_traffic.json"  # ... per launch of the fused block tail at the stage-3 shape
+TRAFFIC_FWD = "r6_attn_fwd_hbm_traffic.json"   # profiles/: PMC HBM bytes per attention launch (tools/traffic.sh via tools/r6_profiles.sh)
+TRAFFIC_BWD = "r6_attn_bwd_hbm_traffic.json"
+TRAFFIC_TAIL = "r6_block_tail_hbm_traffic.json"  # ... per launch of the fused block tail at the stage-3 shape
 
 
 def attention_flops(geoms, B):

@@ -1,5 +1,5 @@
 """Builds profiles/r5_{attn_fwd,attn_bwd,block_tail}_hbm_traffic.json (the files bench.py's `roofline.traffic` reads) from the raw outputs of
-tools/r5_profiles.sh in gpurun_out/:   python tools/r5_assemble_traffic.py <prefix> <commit> [out-prefix = r5]"""
+tools/r5_profiles.sh in gpurun_out/:   python tools/assemble_traffic.py <prefix> <commit> [out-prefix = r5]"""
 import json, os, re, sys
 pre, commit = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else "r5"
@@ -38,4 +38,4 @@ for clips, shp in ((8, "50176x384"), (4, "25088x384"), (3, "18816x384")):
         "traffic_bytes_per_launch": f + w, "algorithmic_bytes_per_launch": a, "clips_per_launch": clips,
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/block_tail_bench.py; FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1"}
 json.dump(tail, open(os.path.join(root, "profiles", "%s_block_tail_hbm_traffic.json" % out), "w"), indent=1)
-print("wrote profiles/r5_{attn_fwd,attn_bwd,block_tail}_hbm_traffic.json")
+print("wrote profiles/%s_{attn_fwd,attn_bwd,block_tail}_hbm_traffic.json" % out)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# GPU box, repo root: tools/r5_profiles.sh <prefix>   -> gpurun_out/<prefix>_*  (the round's evidence set; copy into profiles/, then tools/r5_assemble_traffic.py <prefix> <commit>)
+# GPU box, repo root: COMMIT=<short hash> tools/r6_profiles.sh <prefix>   -> gpurun_out/<prefix>_*  (the round's evidence set; copy into profiles/, then python tools/assemble_traffic.py <prefix> <commit> r6)
+# The commit is passed in by the caller (COMMIT=$(git rev-parse --short HEAD) on the build container: .git does not travel to the GPU box).
 pre=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
-echo "box: $(hostname) $(rocm-smi --showuniqueid 2>/dev/null | grep -i unique | head -1 | awk '{print $NF}') $(date -u +%FT%TZ) commit $(cat .r5_commit 2>/dev/null)" > gpurun_out/${pre}_box.txt
+echo "box: $(hostname) $(rocm-smi --showuniqueid 2>/dev/null | grep -i unique | head -1 | awk '{print $NF}') $(date -u +%FT%TZ) commit ${COMMIT:-unrecorded}" > gpurun_out/${pre}_box.txt
 (python -m pytest tests -q -m gpu -s 2>&1 | grep -vE "socket.cpp|^\[Gloo\]" | sed -E "s/^\.+//" | grep -E "\[[a-z0-9_ ,.=]+\]|^ +[0-9]+ +[0-9]+|worst|error|gate|passed|failed|skipped" ) > gpurun_out/${pre}_gputest_verbose.txt
 python bench.py > gpurun_out/${pre}_bench_train_bs8_448.json 2> gpurun_out/${pre}_bench_train.err
 python bench.py --mode loop --no-cpu-baseline > gpurun_out/${pre}_bench_loop.json 2> /dev/null
