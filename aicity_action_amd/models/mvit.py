@@ -388,7 +388,13 @@ class MViT(nn.Module):
         outs = []
         self._substreams_active = True
         try:
-            for st_, part in zip(self._side_streams, torch.tensor_split(clip, ns, dim=0)):     # balanced: 7 clips on 3 streams = 3, 2, 2
+            parts = torch.tensor_split(clip, ns, dim=0)                                        # balanced: 7 clips on 3 streams = 3, 2, 2
+            split_env = os.environ.get("MVIT_STREAM_SPLIT")                                    # probe: explicit sub-batch sizes, e.g. "4,2,2" (profiles/r6_stream_split_ab.txt)
+            if split_env:
+                sizes = [int(v) for v in split_env.split(",")]
+                if sum(sizes) == clip.shape[0] and len(sizes) <= len(self._side_streams):
+                    parts = torch.split(clip, sizes, dim=0)
+            for st_, part in zip(self._side_streams, parts):
                 st_.wait_stream(cur)
                 with torch.cuda.stream(st_):
                     outs.append(self._forward_hip(part.contiguous(), return_logits))
