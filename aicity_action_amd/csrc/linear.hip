@@ -506,7 +506,8 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 #ifndef BIG_ABL
 #define BIG_ABL 0      // timing ablations of linear_big_kernel (tools/r6_big_ab.sh; results invalid): 1 no epilogue stores, 2 no aux loads, 4 aux loads NOT prefetched (round-5 form),
                        // 8 stores as contiguous 1-KiB runs (wrong places, same bytes), 16 aux loads as contiguous 1-KiB runs (wrong data, same bytes),
-                       // 32 one workgroup of a CU in its main loop at a time (per-CU token; results VALID)
+                       // 32 one workgroup of a CU in its main loop at a time (per-CU token; results VALID),
+                       // 64 the second resident workgroup of every CU starts BIG_DELAY x 64 x 127 cycles late (one-time symmetry breaking; results VALID)
 #endif
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
@@ -618,6 +619,16 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     // same way; the second block's is requested at the top of the epilogue, in front of the first block's arithmetic and stores
     constexpr bool PREFETCH_R = sizeof(TO) == 4 && RES && !(BIG_ABL & 4) && !(BIG_ABL & 2);
     [[maybe_unused]] float4 rr_pre[PREFETCH_R ? 3 : 1][PREFETCH_R ? 4 : 1];
+#if BIG_ABL & 64
+#ifndef BIG_DELAY
+#define BIG_DELAY 2
+#endif
+    // first round of workgroups: ids 0..255 land in slot 0 of the 256 CUs, 256..511 in slot 1 (8 XCDs x 32 CUs, round-robin) -- the second slot starts late
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int i = 0; i < BIG_DELAY; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     dma(0, 0);
 #if BIG_ABL & 32
     const unsigned ckey = cu_key();
