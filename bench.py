@@ -243,14 +243,18 @@ def main():
     # ---- in-step cost of the dominant family: one EXTRA step (after the K timed ones) with two HIP events around every fused-attention
     # launch, recorded on the stream the launch goes to (the sub-batch streams of the inference forward included) ------------------------
     instep = None
-    if rank == 0 and not args.no_kernel_timing and args.mode in ("train", "fwd"):
-        _hip.ATT_TIMER = []
+    if not args.no_kernel_timing and args.mode in ("train", "fwd"):
+        # EVERY rank runs the extra step (a DDP train step all-reduces its gradients: rank 0 alone would wait for the others forever);
+        # only rank 0 brackets its launches with events
+        if rank == 0:
+            _hip.ATT_TIMER = []
         try:
             step()
-            torch.cuda.synchronize()
-            rec = _hip.ATT_TIMER
+            barrier()
+            rec = _hip.ATT_TIMER or []
         finally:
             _hip.ATT_TIMER = None
+    if rank == 0 and not args.no_kernel_timing and args.mode in ("train", "fwd"):
         instep = {}
         for kind in ("fwd", "bwd"):
             rows = [(fl, e0.elapsed_time(e1)) for k_, fl, e0, e1 in rec if k_ == kind]

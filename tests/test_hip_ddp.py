@@ -160,7 +160,7 @@ def test_bench_script_two_ranks_gloo_on_one_gpu():
     env = dict(os.environ, MVIT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-kernel-timing", "--no-forward-record"]
+           "--no-cpu-baseline", "--no-forward-record"]       # kernel timing ON, as the driver runs it: the in-step roofline's extra step is a collective (every rank runs it)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -169,6 +169,8 @@ def test_bench_script_two_ranks_gloo_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-2 * d["value"]
     assert d["config"]["parallelism"].startswith("dp2")
+    rl = d["roofline"]          # the in-step figure (events around every attention-backward launch of rank 0's extra step) beside the alone one
+    assert rl["in_step_launches"] == 16 and 0.0 < rl["frac"] <= rl["frac_alone"] * 1.05 and rl["in_step_ms"] > 0
 
 
 def test_bench_script_launches_its_own_ranks():
