@@ -48,6 +48,6 @@ def shard_indices(n, rank=None, world=None, pad=True):
     rank = get_rank() if rank is None else rank
     world = get_world_size() if world is None else world
     idx = list(range(n))
-    if pad and n % world:
-        idx += idx[: world - n % world]
+    if pad and n and n % world:
+        idx = [i % n for i in range(-(-n // world) * world)]      # wraps as often as needed (fewer items than ranks included)
     return idx[rank::world]

@@ -47,6 +47,8 @@ def test_allreduce_gather_and_sharding_world2():
         assert gathered == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5, 0]      # padded by wrapping: equal counts per rank
     assert du.shard_indices(7, 1, 2, pad=False) == [1, 3, 5]
+    assert [du.shard_indices(3, r, 8) for r in range(8)] == [[0], [1], [2], [0], [1], [2], [0], [1]]      # fewer items than ranks: wraps as often as needed
+    assert du.shard_indices(0, 0, 2) == []
     assert du.get_world_size() == 1 and du.get_rank() == 0
 
 
