@@ -85,6 +85,74 @@ def test_ddp_two_ranks_average_equals_full_batch():
     assert worst <= 1e-3, bad[:12]
 
 
+def _worker_n(rank, world, port, q):
+    """One clip per rank out of a batch of `world` clips (the per-GPU batch shrinks, the bucket / all-reduce logic sees `world` ranks)."""
+    import torch.distributed as dist
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.models.build import wrap_ddp
+    from aicity_action_amd.solver import soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z, meta = load_golden("tiny_even")
+    cfg = cfg_for_case(meta, "fp32", train=True)
+    cfg.NUM_GPUS = 1
+    model = build_model(cfg, gpu_id=0).train()
+    load_synth_weights(model, 0)
+    model = wrap_ddp(model, cfg, 0)
+    clip = synth_clip(world, meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    labels = torch.zeros(world, cfg.MODEL.NUM_CLASSES, device="cuda")
+    labels[torch.arange(world), torch.arange(world) % cfg.MODEL.NUM_CLASSES] = 1.0
+    loss = soft_target_cross_entropy(model([clip[rank:rank + 1]]), labels[rank:rank + 1])
+    loss.backward()
+    torch.cuda.synchronize()
+    ones = torch.ones(3)
+    dist.all_reduce(ones)
+    if rank == 0:
+        q.put((ones.tolist(), {k: p.grad.detach().cpu().numpy() for k, p in model.module.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_eight_ranks_average_equals_full_batch():
+    """BASELINE configs[3]'s world size (8 ranks, DistributedDataParallel from build_model's wrap: bucket views, static graph) on the one GPU
+    of this box over gloo: one clip per rank, the averaged gradients equal the single-process step on the 8 clips (slowfast/models/build.py:47-54;
+    the 8 x MI355X RCCL run itself is the driver's)."""
+    import torch.multiprocessing as mp
+    from aicity_action_amd.models import build_model
+    from aicity_action_amd.solver import soft_target_cross_entropy
+    from aicity_action_amd.utils.synth import load_synth_weights, synth_clip
+    z, meta = load_golden("tiny_even")
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    ones, ddp_grads = q.get(timeout=600)
+    for p in ps:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ones == [8.0, 8.0, 8.0]
+    cfg = cfg_for_case(meta, "fp32", train=True)
+    cfg.NUM_GPUS = 1
+    model = build_model(cfg).train()
+    load_synth_weights(model, 0)
+    clip = synth_clip(world, meta["num_frames"], meta["crop"], meta["clip_seed"]).cuda()
+    labels = torch.zeros(world, cfg.MODEL.NUM_CLASSES, device="cuda")
+    labels[torch.arange(world), torch.arange(world) % cfg.MODEL.NUM_CLASSES] = 1.0
+    soft_target_cross_entropy(model([clip]), labels).backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = p.grad.cpu().numpy()
+        worst = max(worst, float(np.abs(ddp_grads[k] - ref).max() / max(1e-4, np.abs(ref).max())))
+    print("DDP(8 ranks, one clip each) vs the 8-clip batch: worst relative grad error %.2e" % worst)
+    assert worst <= 1e-3
+
+
 def _rccl_worker(port, q):
     """world_size 1 over the REAL "nccl" (= RCCL) backend: the communicator, DDP's bucket streams and the fused optimizer run
     exactly as in `bench.py --gpus N` (one rank per GPU is all this box can offer)."""
