@@ -428,7 +428,7 @@ class MViT(nn.Module):
         pe = self.patch_embed.proj
         _hip.check(L.mvit_stem_fwd(_hip.ptr(clip), _hip.ptr(pe.weight), _hip.ptr(pe.bias),
                                    _hip.ptr(self.pos_embed_spatial), _hip.ptr(self.pos_embed_temporal), _hip.ptr(x),
-                                   B, T, S, _hip.F32 if "stem" in self._exact_ops else act, st), "stem")
+                                   B, T, S, _hip.F32 if "stem" in getattr(self, "_exact_ops", ()) else act, st), "stem")
         if taps is not None:
             taps["stem"] = x
         for g, blk in zip(self.geoms, self.blocks):
@@ -517,7 +517,7 @@ class MViT(nn.Module):
         M = B * N
         Cin, Cout, h = g.dim_in, g.dim_out, g.heads
         at = blk.attn
-        ex = self._exact_ops if act != _hip.F32 else frozenset()
+        ex = getattr(self, "_exact_ops", frozenset()) if act != _hip.F32 else frozenset()
         # 1. U = LN1(x)                                                   attention.py:421
         # 2. fused qkv projection, kept token-major [B,N,3*Cout]          attention.py:230-236
         if "qkv" in ex:
