@@ -115,15 +115,23 @@ __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 ? 2 : 1)) void proj_max
         }
     }
     const bf16_t* w_ptr = w + (int64_t)srow * Cin + cch;
-    uint4 rb0, rb1, rb2, rb3, rb4, rb5;
-#define SF_WLOAD(NT, KT) { const bf16_t* wp_ = w_ptr + (int64_t)((NT) * SP_BN) * Cin + (KT) * SP_BK; \
-        rb0 = *reinterpret_cast<const uint4*>(wp_); rb1 = *reinterpret_cast<const uint4*>(wp_ + 16 * Cin); \
-        rb2 = *reinterpret_cast<const uint4*>(wp_ + 32 * Cin); rb3 = *reinterpret_cast<const uint4*>(wp_ + 48 * Cin); \
-        rb4 = *reinterpret_cast<const uint4*>(wp_ + 64 * Cin); rb5 = *reinterpret_cast<const uint4*>(wp_ + 80 * Cin); }
-#define SF_WSTORE() { char* bp_ = sB + s_lds; \
-        *reinterpret_cast<uint4*>(bp_) = rb0; *reinterpret_cast<uint4*>(bp_ + 16 * SP_ROWB) = rb1; *reinterpret_cast<uint4*>(bp_ + 32 * SP_ROWB) = rb2; \
-        *reinterpret_cast<uint4*>(bp_ + 48 * SP_ROWB) = rb3; *reinterpret_cast<uint4*>(bp_ + 64 * SP_ROWB) = rb4; *reinterpret_cast<uint4*>(bp_ + 80 * SP_ROWB) = rb5; }
-    SF_WLOAD(0, 0)
+    // Weight slabs go global -> registers -> LDS.  Round 6: TWO slabs of lead for NK >= 2 (two register sets, alternating by slab parity): with
+    // one slab of lead the L2 latency of a slab (~1.5 k cycles) stood against the 0.24 us of MFMA of the slab in front of it -- a workgroup at
+    // block 14 spent ~59 us on 7.7 us of MFMA.  Same slabs, same order, same MFMA sequence: the results do not change.
+    constexpr int LEAD = NK >= 2 ? 2 : 1;
+    const int nslab = (Cout / SP_BN) * NK;
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;       // (named registers: arrays handed to helper lambdas ended up in scratch)
+    rb0 = rb1 = rb2 = rb3 = rb4 = rb5 = make_uint4(0, 0, 0, 0);
+#define SF_WLOAD(R, J) { const int j_ = (J); if (j_ < nslab) { const int nt_ = j_ / NK, kt_ = j_ - nt_ * NK; \
+        const bf16_t* wp_ = w_ptr + (int64_t)(nt_ * SP_BN) * Cin + kt_ * SP_BK; \
+        R##0 = *reinterpret_cast<const uint4*>(wp_); R##1 = *reinterpret_cast<const uint4*>(wp_ + 16 * Cin); \
+        R##2 = *reinterpret_cast<const uint4*>(wp_ + 32 * Cin); R##3 = *reinterpret_cast<const uint4*>(wp_ + 48 * Cin); \
+        R##4 = *reinterpret_cast<const uint4*>(wp_ + 64 * Cin); R##5 = *reinterpret_cast<const uint4*>(wp_ + 80 * Cin); } }
+#define SF_WSTORE(R) { char* bp_ = sB + s_lds; \
+        *reinterpret_cast<uint4*>(bp_) = R##0; *reinterpret_cast<uint4*>(bp_ + 16 * SP_ROWB) = R##1; *reinterpret_cast<uint4*>(bp_ + 32 * SP_ROWB) = R##2; \
+        *reinterpret_cast<uint4*>(bp_ + 48 * SP_ROWB) = R##3; *reinterpret_cast<uint4*>(bp_ + 64 * SP_ROWB) = R##4; *reinterpret_cast<uint4*>(bp_ + 80 * SP_ROWB) = R##5; }
+    SF_WLOAD(ra, 0)
+    if constexpr (LEAD == 2) SF_WLOAD(rb, 1)
 
     int foff[6];
 #pragma unroll
@@ -158,15 +166,13 @@ __global__ __launch_bounds__(256, NK == 1 ? 3 : (NK == 2 ? 2 : 1)) void proj_max
         for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            __syncthreads();                  // sB / the stage are free (and, first time round, the A slabs are about to be complete)
-            if (s_on) SF_WSTORE()
-            __syncthreads();
-            if (kt + 1 < NK) SF_WLOAD(nt, kt + 1)
-            else if (nt + 1 < ntn) SF_WLOAD(nt + 1, 0)
-            sp_slab_mfma(fa + kt * (SP_ROWS * SP_ROWB), fb, foff, acc);
-        }
+#define SF_SLAB(KT, R) { __syncthreads(); if (s_on) SF_WSTORE(R) __syncthreads(); SF_WLOAD(R, nt * NK + (KT) + LEAD) \
+                         sp_slab_mfma(fa + (KT) * (SP_ROWS * SP_ROWB), fb, foff, acc); }
+        // (first barrier: sB / the stage are free and, first time round, the A slabs are about to be complete; second: the slab is in place)
+        if constexpr (NK == 1) { SF_SLAB(0, ra) }
+        else if constexpr (NK == 2) { SF_SLAB(0, ra) SF_SLAB(1, rb) }
+        else { SF_SLAB(0, ra) SF_SLAB(1, rb) SF_SLAB(2, ra) SF_SLAB(3, rb) }
+#undef SF_SLAB
         // window maxima, 32 columns per pass; the first maximum in ATen's scan order (ky, kx) among the in-frame taps is recorded
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
