@@ -467,9 +467,9 @@ extern "C" int mvit_side_join(void* stream) {
 }
 
 #ifdef MVIT_HALF_IS_FP16
-extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r5 (16-bit type: fp16)"; }
+extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r6 (16-bit type: fp16)"; }
 #else
-extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r5 (16-bit type: bf16)"; }
+extern "C" const char* mvit_version(void) { return "mvit-hip gfx950 r6 (16-bit type: bf16)"; }
 #endif
 
 extern "C" const char* mvit_strerror(int code) {
