@@ -507,7 +507,8 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 #define BIG_ABL 0      // timing ablations of linear_big_kernel (tools/r6_big_ab.sh; results invalid): 1 no epilogue stores, 2 no aux loads, 4 aux loads NOT prefetched (round-5 form),
                        // 8 stores as contiguous 1-KiB runs (wrong places, same bytes), 16 aux loads as contiguous 1-KiB runs (wrong data, same bytes),
                        // 32 one workgroup of a CU in its main loop at a time (per-CU token; results VALID),
-                       // 64 the second resident workgroup of every CU starts BIG_DELAY x 64 x 127 cycles late (one-time symmetry breaking; results VALID)
+                       // 64 the second resident workgroup of every CU starts BIG_DELAY x 64 x 127 cycles late (one-time symmetry breaking; results VALID),
+                       // 128 the first round's workgroups of XCD k start k x BIG_DELAY x 2560 cycles late (results VALID)
 #endif
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
@@ -627,6 +628,16 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     if (blockIdx.x >= 256 && blockIdx.x < 512) {
 #pragma unroll 1
         for (int i = 0; i < BIG_DELAY; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+#if BIG_ABL & 128
+#ifndef BIG_DELAY
+#define BIG_DELAY 2
+#endif
+    // probe: the first round's workgroups of XCD k (= blockIdx.x % 8) start k x BIG_DELAY x 2560 cycles late: the eight XCDs' store bursts no longer coincide
+    if (blockIdx.x < 512) {
+#pragma unroll 1
+        for (int i = 0; i < (int)(blockIdx.x & 7) * BIG_DELAY; ++i) __builtin_amdgcn_s_sleep(40);
     }
 #endif
     dma(0, 0);
