@@ -508,10 +508,17 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
                        // 8 stores as contiguous 1-KiB runs (wrong places, same bytes), 16 aux loads as contiguous 1-KiB runs (wrong data, same bytes),
                        // 32 one workgroup of a CU in its main loop at a time (per-CU token; results VALID),
                        // 64 the second resident workgroup of every CU starts BIG_DELAY x 64 x 127 cycles late (one-time symmetry breaking; results VALID),
-                       // 128 the first round's workgroups of XCD k start k x BIG_DELAY x 2560 cycles late (results VALID)
+                       // 128 the first round's workgroups of XCD k start k x BIG_DELAY x 2560 cycles late (results VALID),
+                       // 256 s_memrealtime stamps (100 MHz, chip-wide) at workgroup start / main-loop end / kernel end + the CU id, read back by mvit_debug_big_stamps (results VALID)
 #endif
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
+#if BIG_ABL & 256
+__device__ unsigned long long g_big_stamps[8192 * 4];
+extern "C" __attribute__((visibility("default"))) int mvit_debug_big_stamps(unsigned long long* out) {      /* tools/r6_big_stamps.py only; not part of the C-ABI */
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -3;
+}
+#endif
 #if BIG_ABL & 32
 // Probe: a per-CU token around the main loop.  The two workgroups of a CU share the matrix pipes, which pulls them into lock-step (the
 // one ahead slows down whenever both multiply, the one behind speeds up whenever the other stores): main loops together, then epilogues
@@ -540,6 +547,9 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
+#if BIG_ABL & 256
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const bool full_m = m0 + G_BM <= M;
 
     // DMA piece p (1 KiB = 8 rows x 128 B): lane -> row 8p + lane/8, position lane%8, logical chunk pos ^ swz(row)
@@ -714,6 +724,20 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
 #if BIG_ABL & 32
     __builtin_amdgcn_s_barrier();
     if (tid == 0) atomicExch(&g_cu_token[ckey], 0u);
+#endif
+#if BIG_ABL & 256
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
+    struct StampAtExit {
+        unsigned long long t0, t1; unsigned bid; int tid;
+        __device__ ~StampAtExit() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the epilogue's stores have been acknowledged
+            if (tid == 0 && bid < 8192) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+                g_big_stamps[4 * bid] = t0; g_big_stamps[4 * bid + 1] = t1; g_big_stamps[4 * bid + 2] = __builtin_amdgcn_s_memrealtime();
+                g_big_stamps[4 * bid + 3] = (unsigned long long)((xcc & 15u) * 256u + ((hw >> 8) & 255u));
+            }
+        }
+    } stamp_at_exit{st_t0, st_t1, blockIdx.x, tid};
 #endif
     if (epilogue & 256) {   // DIAG build aid: skip the epilogue, keep the accumulators live
         float t = 0.f;
