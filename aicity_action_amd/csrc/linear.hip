@@ -514,9 +514,9 @@ __device__ __forceinline__ void lds_wait5(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 // DG (16-bit out only): `residual` carries the 16-bit pre-activation of the MLP (row stride ldr) and the result is multiplied by
 // GELU'(pre): the data gradient of fc2 leaves the GEMM as the gradient of fc1's output (no separate element-wise pass)
 #if BIG_ABL & 256
-__device__ unsigned long long g_big_stamps[8192 * 4];
+__device__ unsigned long long g_big_stamps[8192 * 8];
 extern "C" __attribute__((visibility("default"))) int mvit_debug_big_stamps(unsigned long long* out) {      /* tools/r6_big_stamps.py only; not part of the C-ABI */
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_stamps), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -3;
 }
 #endif
 #if BIG_ABL & 32
@@ -650,6 +650,88 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         for (int i = 0; i < (int)(blockIdx.x & 7) * BIG_DELAY; ++i) __builtin_amdgcn_s_sleep(40);
     }
 #endif
+#ifndef BIG_PIPE
+#define BIG_PIPE 1      // slabs in flight: 1 = the product's loop; 2 = the two-slab probe of round 6 (below; -DBIG_PIPE=2)
+#endif
+#if BIG_PIPE == 2
+    // PROBE, not the product (profiles/r6_gemm_big_pipe_ab.txt: fc2 data gradient +3-5 %, long-K residual -2-4 %, train step unchanged).
+    // TWO slabs in flight on TWO LDS buffers (round 6).  The stamps of profiles/r6_gemm_big_stamps.txt put a K-tile at 2.0 us of which the 24 MFMAs are 0.36 us:
+    // with one slab of lead (requested at the top of iteration kt, awaited at the top of kt + 1) an iteration cannot be shorter than the LDS-DMA's issue-to-landed
+    // time (~1.1 us, MI355X_MICROARCH.md) and a CU's two workgroups keep ~40 KB in flight, 40 GB/s.  Here a wave reads ALL 20 fragments of slab kt into registers
+    // first (it holds them all anyway), a second barrier says the buffer is free, and slab kt + 2 is requested into it BEFORE the MFMAs of slab kt: a request has
+    // an iteration and a half to land, two slabs per workgroup are in flight.  Same slabs, same k order per accumulator: results bit-identical.
+    auto k0_of = [&](int s_) { return (ktail && s_ + 1 == nk) ? K - G_BK : s_ * G_BK; };
+    dma(0, 0);
+    if (nk > 1) dma(k0_of(1), 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of slab kt have landed; younger and allowed to fly: slab kt + 1 (10 pieces) and, in iterations 1 and 2, the 12 epilogue-operand
+        // loads requested in iteration 0 (vmcnt retires in order; they sit between slab 2 and slab 3 in the issue order)
+        {
+            const int young = ((kt + 1 < nk) ? 10 : 0) + (((PREFETCH || PREFETCH_R) && (kt == 1 || kt == 2)) ? 12 : 0);
+            if (young == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else if (young == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (young == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                      // everyone's pieces of slab kt have landed
+        const bool half = ktail && kt + 1 == nk;
+        const uint32_t bo = (kt & 1) ? G_BUF : 0;
+        bf16x8 xf[4][2], wf[4][3];
+#define RD(KS) { const uint32_t xa = lds_x[KS] + bo, wa = lds_w[KS] + bo; \
+                 xf[KS][0] = lds_read128<0>(xa); xf[KS][1] = lds_read128<32 * G_ROWB>(xa); \
+                 wf[KS][0] = lds_read128<0>(wa); wf[KS][1] = lds_read128<32 * G_ROWB>(wa); wf[KS][2] = lds_read128<64 * G_ROWB>(wa); }
+#define MM(KS) _Pragma("unroll") for (int nb = 0; nb < 3; ++nb) _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) \
+                 acc[mb][nb] = mfma16(wf[KS][nb], xf[KS][mb], acc[mb][nb]);
+        RD(0) RD(1) RD(2) RD(3)
+        lds_wait5<0>(xf[0][0], xf[0][1], wf[0][0], wf[0][1], wf[0][2]);
+        lds_wait5<0>(xf[1][0], xf[1][1], wf[1][0], wf[1][1], wf[1][2]);
+        lds_wait5<0>(xf[2][0], xf[2][1], wf[2][0], wf[2][1], wf[2][2]);
+        lds_wait5<0>(xf[3][0], xf[3][1], wf[3][0], wf[3][1], wf[3][2]);
+        __builtin_amdgcn_s_barrier();                      // every wave holds its fragments of slab kt: buffer kt & 1 is free
+        if (kt + 2 < nk) dma(k0_of(kt + 2), kt & 1);
+        if constexpr (PREFETCH) {
+            if (kt == 0) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    int64_t m = m0 + 64 * wm + 32 * mb + r;
+                    m = (full_m || m < M) ? m : M - 1;
+                    const bf16_t* pre = reinterpret_cast<const bf16_t*>(residual) + m * ldr + n0 + 96 * wn;
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            if constexpr (BIG_ABL & 16) {
+                                const int run = ((wave * 2 + mb) * 3 + nb) * 2 + qq, piece = run * 64 + lane;
+                                const int prow = piece / 24, pc = piece - prow * 24;
+                                pre_all[mb][nb][qq] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(residual) + (m0 + prow) * ldr + n0 + 8 * pc);
+                            } else
+                            pre_all[mb][nb][qq] = *reinterpret_cast<const uint4*>(pre + 32 * nb + 8 * (2 * qq + h));
+                        }
+                }
+            }
+        }
+        if constexpr (PREFETCH_R) {
+            if (kt == 0) {
+                int64_t m = m0 + 64 * wm + r;
+                m = (full_m || m < M) ? m : M - 1;
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rr_pre[nb][q] = load4(residual + m * ldr + n0 + 96 * wn + 32 * nb + 4 * h + 8 * q);
+            }
+        }
+        if (half) { xf[0][0] = bf16x8{}; xf[0][1] = bf16x8{}; xf[1][0] = bf16x8{}; xf[1][1] = bf16x8{}; }
+        MM(0)
+        __builtin_amdgcn_sched_barrier(0);
+        MM(1)
+        __builtin_amdgcn_sched_barrier(0);
+        MM(2)
+        __builtin_amdgcn_sched_barrier(0);
+        MM(3)
+#undef RD
+#undef MM
+    }
+#else
     dma(0, 0);
 #if BIG_ABL & 32
     const unsigned ckey = cu_key();
@@ -657,11 +739,21 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         while (atomicCAS(&g_cu_token[ckey], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(4);
     }
 #endif
+#if BIG_ABL & 256
+    unsigned long long ph_wait = 0, ph_bar = 0, ph_dma = 0, ph_mm = 0;
+#define PH_T(v) const unsigned long long v = __builtin_readcyclecounter();
+#else
+#define PH_T(v)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        PH_T(p0_)
         if ((PREFETCH || PREFETCH_R) && kt == 1 && nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // slab 1 has landed; the 12 younger loads may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of slab kt have landed
+        PH_T(p1_)
         __builtin_amdgcn_s_barrier();                      // everyone's have; everyone is done reading the other buffer
+        PH_T(p2_)
         if (kt + 1 < nk) dma((ktail && kt + 2 == nk) ? K - G_BK : (kt + 1) * G_BK, (kt + 1) & 1);
+        PH_T(p3_)
         if constexpr (PREFETCH) {
             if (kt == 0) {
 #pragma unroll
@@ -719,8 +811,12 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
         MM(3)
 #undef RD
 #undef MM
+#if BIG_ABL & 256
+        { const unsigned long long p4_ = __builtin_readcyclecounter(); ph_wait += p1_ - p0_; ph_bar += p2_ - p1_; ph_dma += p3_ - p2_; ph_mm += p4_ - p3_; }
+#endif
     }
 
+#endif      // BIG_PIPE
 #if BIG_ABL & 32
     __builtin_amdgcn_s_barrier();
     if (tid == 0) atomicExch(&g_cu_token[ckey], 0u);
@@ -728,16 +824,23 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(
 #if BIG_ABL & 256
     const unsigned long long st_t1 = __builtin_amdgcn_s_memrealtime();
     struct StampAtExit {
-        unsigned long long t0, t1; unsigned bid; int tid;
+        unsigned long long t0, t1; unsigned bid; int tid; unsigned long long pw, pb, pd, pm;
         __device__ ~StampAtExit() {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the epilogue's stores have been acknowledged
             if (tid == 0 && bid < 8192) {
                 const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-                g_big_stamps[4 * bid] = t0; g_big_stamps[4 * bid + 1] = t1; g_big_stamps[4 * bid + 2] = __builtin_amdgcn_s_memrealtime();
-                g_big_stamps[4 * bid + 3] = (unsigned long long)((xcc & 15u) * 256u + ((hw >> 8) & 255u));
+                g_big_stamps[8 * bid] = t0; g_big_stamps[8 * bid + 1] = t1; g_big_stamps[8 * bid + 2] = __builtin_amdgcn_s_memrealtime();
+                g_big_stamps[8 * bid + 3] = (unsigned long long)((xcc & 15u) * 256u + ((hw >> 8) & 255u));
+                g_big_stamps[8 * bid + 4] = pw; g_big_stamps[8 * bid + 5] = pb; g_big_stamps[8 * bid + 6] = pd; g_big_stamps[8 * bid + 7] = pm;
             }
         }
-    } stamp_at_exit{st_t0, st_t1, blockIdx.x, tid};
+    } stamp_at_exit{st_t0, st_t1, blockIdx.x, tid,
+#if BIG_PIPE == 1
+                    ph_wait, ph_bar, ph_dma, ph_mm
+#else
+                    0, 0, 0, 0
+#endif
+    };
 #endif
     if (epilogue & 256) {   // DIAG build aid: skip the epilogue, keep the accumulators live
         float t = 0.f;

@@ -35,10 +35,10 @@ for _ in range(5):
 torch.cuda.synchronize()
 fn()
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (8192 * 4))()
+buf = (ctypes.c_ulonglong * (8192 * 8))()
 L.mvit_debug_big_stamps.restype = ctypes.c_int
 assert L.mvit_debug_big_stamps(buf) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
 nwg = ((M + 127) // 128) * (N // 192)
 a = a[:min(nwg, 8192)]
 t0, t1, t2, cu = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
@@ -47,6 +47,11 @@ span = (t2.max() - base) / 100.0
 print("%s M=%d N=%d K=%d: %d workgroups stamped, launch span %.1f us on the 100 MHz clock, %d distinct CUs" % (mode, M, N, K, len(a), span, len(set(cu.tolist()))))
 print("per workgroup: main loop (start -> last MFMA issued) %.2f us mean (p10 %.2f, p90 %.2f); epilogue (-> stores acknowledged) %.2f us mean (p10 %.2f, p90 %.2f)" % (
     (t1 - t0).mean() / 100, np.percentile(t1 - t0, 10) / 100, np.percentile(t1 - t0, 90) / 100, (t2 - t1).mean() / 100, np.percentile(t2 - t1, 10) / 100, np.percentile(t2 - t1, 90) / 100))
+ph = a[:, 4:8].astype(np.float64)
+if ph.sum() > 0:
+    nkt = (K + 63) // 64
+    print("wave 0 of a workgroup, shader cycles per K-tile (%d K-tiles): wait for the slab's DMA %.0f, barrier %.0f, issue of the next slab's %d LDS-DMA pieces (+ operand prefetch) %.0f, "
+          "fragment reads + 24 MFMAs %.0f  (sum %.0f)" % (nkt, ph[:, 0].mean() / nkt, ph[:, 1].mean() / nkt, 10, ph[:, 2].mean() / nkt, ph[:, 3].mean() / nkt, ph.sum(1).mean() / nkt))
 # per CU occupancy of the two phases over the launch span (10 ns ticks)
 T = int(t2.max() - base) + 1
 tot = collections.Counter()
